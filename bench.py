@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Benchmark of the FDTD field-update path on MI355X.
+
+One "step" is one full time step (H, D, source, E, Mur) of one slab.  At
+--gpus 1 the workload is BASELINE.json's configs[1]: a 16384 x 16384 2-D TMz
+grid, vacuum, one point source at the centre.  At --gpus N every rank holds a
+16384 x 16384 slab of a 16384 x (16384*N) grid (weak scaling) and exchanges one
+ez row with each neighbour per step over RCCL.  The metric is
+Mcell-updates/s = cells * steps / seconds / 1e6, whole job.
+
+Prints one JSON line (rank 0) with the roofline of the dominant kernel (HBM
+bound; 41 algorithmic bytes per 2-D cell-update) measured with HIP events on
+the library's stream, and -- at one GPU -- the CPU oracle timed on the host
+cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_CELL_2D = 41   # read hx hy ez^n ez^n-1 dz^n dz^n-1 (24) + code (1); write hx hy ez dz (16)
+BYTES_PER_CELL_3D = 97   # read 3 H + 6 E + 6 D (60) + code (1); write 3 H + 3 E + 3 D (36)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak
+
+
+def cpu_baseline(nx, ny, budget_s=12.0):
+    """Oracle (CPU restatement, OpenMP over rows) on a bounded sample: the same
+    vacuum + centre-source workload on a smaller grid for about budget_s seconds."""
+    from oracle import oracle
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    p = oracle.make_params(nx, ny, 1, [(nx // 2, ny // 2, 0)])
+    o = oracle.Oracle(p, ecoef=oracle.ECOEF_CONSISTENT)
+    o.step(2, threads)                                   # touch the pages
+    t_probe = o.time_steps(3, threads) / 3
+    steps = max(3, min(2000, int(budget_s / max(t_probe, 1e-6))))
+    sec = o.time_steps(steps, threads)
+    return {
+        "value": nx * ny * steps / sec / 1e6,
+        "unit": "Mcell-updates/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"CPU oracle (C, -O2 -ffp-contract=off, OpenMP), {nx}x{ny} 2-D TMz vacuum + centre source, "
+                  f"{steps} steps, {sec:.1f} s",
+    }
+
+
+def measured_traffic(workload):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes, if any."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--nx", type=int, default=16384)
+    ap.add_argument("--ny", type=int, default=16384, help="rows per GPU")
+    ap.add_argument("--nz", type=int, default=1, help="> 1 selects the 3-D path (z planes per GPU)")
+    ap.add_argument("--chunk-rows", type=int, default=0)
+    ap.add_argument("--kernel", choices=["auto", "split", "fused"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import fdtd_amd
+    from fdtd_amd import binding as B
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        # control plane (rendezvous, barrier, max over ranks) on gloo; the data plane
+        # is the library's own RCCL communicator (ncclSend/ncclRecv of halo rows)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    is3d = args.nz > 1
+    nx = args.nx
+    if is3d:
+        gdims = (nx, args.ny, args.nz * world)
+        slab = (rank * args.nz, args.nz)
+        src = [(nx // 2, args.ny // 2, gdims[2] // 2)]
+        cells_per_rank = nx * args.ny * args.nz
+        bytes_per_cell = BYTES_PER_CELL_3D
+    else:
+        gdims = (nx, args.ny * world, 1)
+        slab = (rank * args.ny, args.ny)
+        src = [(nx // 2, gdims[1] // 2, 0)]
+        cells_per_rank = nx * args.ny
+        bytes_per_cell = BYTES_PER_CELL_2D
+    params = fdtd_amd.make_params(*gdims, src)
+    kernel = {"auto": B.KERNEL_AUTO, "split": B.KERNEL_SPLIT, "fused": B.KERNEL_FUSED}[args.kernel]
+    solver = fdtd_amd.Solver(params, ecoef=B.ECOEF_CONSISTENT, kernel=kernel, device=local_rank,
+                             slab=slab if world > 1 else None, chunk_rows=args.chunk_rows)
+    if world > 1:
+        ids = [fdtd_amd.binding.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        solver.comm_init(ids[0], rank, world)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    solver.step(args.warmup)
+    solver.profile_begin(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    solver.step(args.steps)
+    solver.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    sweep_ms = solver.profile_read(args.steps)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    ez = None
+    if rank == 0:
+        # the run must have moved real data: the field around the source is finite and non-zero
+        probe = solver.field(B.EZ) if cells_per_rank <= 2 ** 28 else None
+        if probe is not None:
+            ez = float(np.abs(probe).max())
+            assert np.isfinite(ez) and (ez > 0 or world > 1), "field is zero or not finite after the run"
+
+    if rank == 0:
+        total_cells = cells_per_rank * world
+        value = total_cells * args.steps / elapsed / 1e6
+        sweep_avg_ms = float(np.mean(sweep_ms)) if len(sweep_ms) else float("nan")
+        achieved = cells_per_rank * bytes_per_cell / (sweep_avg_ms * 1e-3) / 1e9
+        workload = (f"{gdims[0]}x{gdims[1]}x{gdims[2]} 3-D" if is3d else f"{gdims[0]}x{gdims[1]} 2-D TMz") + \
+            " vacuum + centre point source"
+        out = {
+            "metric": "Mcell-updates/s (E+H)",
+            "value": value,
+            "unit": "Mcell-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": workload,
+                "cells_per_gpu": cells_per_rank,
+                "ecoef": "consistent",
+                "kernel": solver.sweep_kernel_name,
+                "parallelism": f"slab{world}" if world > 1 else "single",
+                "halo": "RCCL send/recv, 1 ez row per neighbour per step" if world > 1 else "none",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(workload),
+                "kernel": solver.sweep_kernel_name,
+                "kernel_avg_ms": sweep_avg_ms,
+                "algorithmic_bytes_per_cell": bytes_per_cell,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(4096, 4096) if not is3d else None
+        print(json.dumps(out), flush=True)
+
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

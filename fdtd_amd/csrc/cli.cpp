@@ -1,0 +1,163 @@
+// `fdtd` -- command-line driver with the invocation shape of the reference
+// (fdtd.cu:46-544): run from the directory that holds data/, no arguments
+// needed; reads data/input_params, data/mat_specs_riken and the PGM slices of
+// env_set_dir, steps the fields on the GPU through the C ABI and writes
+// <output_dir>/{H,D,E}_field_{x,y,z}_%05d_z%05d.out like writeResults3d
+// (fdtd.cu:1288-1494).  Errors print a message and exit(EXIT_FAILURE), the
+// convention of the reference's CHECK macro (utils.h:5-13).
+//
+// Extensions (all optional):
+//   --params PATH        parameter file (default data/input_params)
+//   --specs PATH         material specs (default data/mat_specs_riken)
+//   --mode 2d|3d         default: 2d when nz = 1
+//   --ecoef reference|consistent
+//   --first-slice N      1-based PGM index used for z = 0 (default 1)
+//   --upsample U         repeat each PGM pixel U x U times
+//   --no-materials       keep the fsigma/feps_s/feps_inf/ftau_d defaults everywhere
+//   --output-every N     write fields every N steps (default 1, 0 = never)
+//   --device N
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fdtd_amd.h"
+
+static void die(const char *what)
+{
+    std::printf("Error: %s: %s\n", what, fdtd_last_error());
+    std::exit(EXIT_FAILURE);
+}
+
+// printParams, fdtd.cu:648-667
+static void print_params(const fdtd_params &p)
+{
+    std::printf("Field size:                 %04dx%04dx%04d\n", p.nx, p.ny, p.nz);
+    std::printf("Iterations count:           %d\n", p.iterations);
+    std::printf("Input path:                 %s\n", p.input_path);
+    std::printf("Output path:                %s\n", p.output_path);
+    std::printf("Elements per wavelength:    %d\n", p.elements_per_wave);
+    std::printf("Wave frequency:             %9.3E\n", p.wave_frequency);
+    std::printf("Pulse width:                %9.3E\n", p.pulse_width);
+    std::printf("Pulse modulation frequency: %9.3E\n", p.pulse_modulation_frequency);
+    std::printf("Sources count:              %d\n", p.sources_count);
+    for (int i = 0; i < p.sources_count; i++)
+        std::printf("Source position:            %04dx%04dx%04d\n", p.sources[i * 3] + 1, p.sources[i * 3 + 1] + 1,
+                    p.sources[i * 3 + 2] + 1);
+    std::printf("Default sigma:              %9.3E\n", p.default_sigma);
+    std::printf("Default eps_s:              %9.3E\n", p.default_eps_s);
+    std::printf("Default eps_i:              %9.3E\n", p.default_eps_i);
+    std::printf("Default tau_d:              %9.3E\n", p.default_tau_d);
+    std::printf("\n");
+}
+
+// One field of one step: nz files of ny lines of nx values " % 9.3E"
+// (fdtd.cu:1302-1318); `iteration` is the 0-based step index.
+static void write_field(const fdtd_params &p, const char *family, char axis, int iteration,
+                        const std::vector<float> &data)
+{
+    std::string line;
+    char num[32];
+    for (int iz = 0; iz < p.nz; iz++) {
+        char path[2304];
+        std::snprintf(path, sizeof path, "%s/%s_field_%c_%05d_z%05d.out", p.output_path, family, axis, iteration, iz);
+        FILE *f = std::fopen(path, "w");
+        if (!f) {
+            std::printf("Couldn't open file %s\n", path);
+            std::exit(EXIT_FAILURE);
+        }
+        for (int iy = 0; iy < p.ny; iy++) {
+            line.clear();
+            const float *row = &data[((size_t)iz * p.ny + iy) * p.nx];
+            for (int ix = 0; ix < p.nx; ix++) {
+                std::snprintf(num, sizeof num, " % 9.3E", row[ix]);
+                line += num;
+            }
+            line += '\n';
+            std::fwrite(line.data(), 1, line.size(), f);
+        }
+        std::fclose(f);
+    }
+}
+
+int main(int argc, char **argv)
+{
+    std::string params_path = "data/input_params", specs_path = "data/mat_specs_riken";
+    fdtd_options opt;
+    fdtd_options_default(&opt);
+    int first_slice = 1, upsample = 1, output_every = 1;
+    bool materials = true;
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto value = [&]() -> const char * {
+            if (i + 1 >= argc) {
+                std::printf("Error: %s needs a value\n", a.c_str());
+                std::exit(EXIT_FAILURE);
+            }
+            return argv[++i];
+        };
+        if (a == "--params") params_path = value();
+        else if (a == "--specs") specs_path = value();
+        else if (a == "--mode") opt.mode = std::strcmp(value(), "2d") == 0 ? FDTD_MODE_2D_TMZ : FDTD_MODE_3D;
+        else if (a == "--ecoef")
+            opt.ecoef = std::strcmp(value(), "consistent") == 0 ? FDTD_ECOEF_CONSISTENT : FDTD_ECOEF_REFERENCE;
+        else if (a == "--first-slice") first_slice = std::atoi(value());
+        else if (a == "--upsample") upsample = std::atoi(value());
+        else if (a == "--no-materials") materials = false;
+        else if (a == "--output-every") output_every = std::atoi(value());
+        else if (a == "--device") opt.device = std::atoi(value());
+        else {
+            std::printf("Error: unknown argument %s\n", a.c_str());
+            return EXIT_FAILURE;
+        }
+    }
+
+    std::printf("Reading parameters...\n");
+    fdtd_params p;
+    if (fdtd_params_load(params_path.c_str(), &p)) die("reading parameters");
+    print_params(p);
+
+    std::printf("Initializing device field...\n");
+    fdtd_ctx *ctx = nullptr;
+    if (fdtd_create(&p, &opt, &ctx)) die("initializing device field");
+
+    if (materials) {
+        std::printf("Reading materials data...\n");
+        if (fdtd_load_materials(ctx, specs_path.c_str(), p.input_path, first_slice, upsample))
+            die("reading materials data");
+    }
+    std::printf("Initializing sources...\n\n");
+
+    const bool is2d = opt.mode == FDTD_MODE_2D_TMZ || (opt.mode == FDTD_MODE_AUTO && p.nz == 1);
+    const size_t cells = (size_t)p.nx * p.ny * p.nz;
+    std::vector<float> host(cells);
+    static const char *family[3] = {"H", "D", "E"};
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < p.iterations; i++) {
+        std::printf("Running iteration %d\n", i + 1);
+        if (fdtd_step(ctx, 1)) die("stepping");
+        if (output_every > 0 && i % output_every == 0) {
+            std::printf("Writing results for iteration %d\n", i + 1);
+            for (int fam = 0; fam < 3; fam++)
+                for (int k = 0; k < 3; k++) {
+                    const int field = fam * 3 + k;
+                    const bool held = !is2d || field == FDTD_HX || field == FDTD_HY || field == FDTD_DZ || field == FDTD_EZ;
+                    if (held) {
+                        if (fdtd_read_field(ctx, field, 0, host.data(), cells)) die("reading a field");
+                    } else {
+                        std::fill(host.begin(), host.end(), 0.0f);
+                    }
+                    write_field(p, family[fam], "xyz"[k], i, host);
+                }
+        }
+    }
+    if (fdtd_sync(ctx)) die("synchronizing");
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("\n%d iterations, %.3f s, %.1f Mcell-updates/s (I/O included)\n", p.iterations, sec,
+                (double)cells * p.iterations / sec / 1e6);
+    fdtd_destroy(ctx);
+    return 0;
+}

@@ -1,0 +1,887 @@
+// The solver context behind the C ABI (include/fdtd_amd.h): device storage,
+// the per-step schedule, field/probe/snapshot transfers.
+//
+// Storage.  Every field is its own padded array in HBM (SoA): rows of `pitch`
+// floats (a multiple of 64, so every row starts on a 256-byte line), one halo
+// row (2-D, y axis) or halo plane (3-D, z axis) on either side of the slab.
+// E and D keep two time levels: level n+1 is written over level n-1 once the
+// cell's E update has consumed it (the reference rotates three buffers,
+// fdtd.cu:206-211; cells it never writes are zero in all three, so two levels
+// give the same values).  Materials are one byte per cell plus a table of at
+// most 256 coefficient rows instead of four floats per cell.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "comm.h"
+#include "internal.h"
+
+using namespace fdtd;
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) {                                                                   \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                         \
+            return -10;                                                                           \
+        }                                                                                         \
+    } while (0)
+
+namespace {
+constexpr size_t kSlack = 256; // floats (or bytes) of zero padding around each array
+}
+
+struct fdtd_ctx {
+    fdtd_params p;
+    int mode = FDTD_MODE_3D;
+    int kernel = FDTD_KERNEL_SPLIT;
+    int ecoef = FDTD_ECOEF_REFERENCE;
+    int device = 0;
+    hipStream_t stream = nullptr, side = nullptr;
+
+    int nx = 0, ny = 0, nz = 0; // global extents
+    int s0 = 0, sn = 0, gn = 0; // slab axis: first global row held, rows held, global rows
+    int pitch = 0;
+    size_t rows_store = 0; // storage rows per array (halo rows included)
+    size_t elems = 0;      // floats per array without the slack
+    int chunk_rows = 64;
+
+    std::vector<void *> allocs;
+    float *h[3][2] = {};
+    float *e[3][2] = {};
+    float *d[3][2] = {};
+    uint8_t *code = nullptr;
+    MatCoef *table = nullptr;
+    float *rp[6] = {};
+    size_t rp_n[6] = {};
+
+    int cur = 0;  // index of the newest E/D level
+    int hgen = 0; // index of the newest H generation
+    int64_t step = 0;
+
+    MaterialRow mats[FDTD_MAX_CODES];
+    int ntab = FDTD_MAX_CODES;
+    std::vector<uint8_t> codes_host; // slab cells, x fastest; empty = all default
+    std::vector<float> rp_host[6];
+    SourceList src; // global coordinates
+
+    // probes
+    ProbeList probes = {};
+    float *probe_ring = nullptr;
+    int probe_cap = 0;
+    int64_t probe_first = 0; // step index of the oldest row the ring may hold
+
+    // per-step sweep timing
+    std::vector<hipEvent_t> prof_ev;
+    int prof_cap = 0, prof_n = 0;
+
+    // snapshot
+    float *snap_dev = nullptr, *snap_host = nullptr;
+    size_t snap_count = 0;
+    float *snap_dst = nullptr;
+    bool snap_pending = false;
+    hipEvent_t snap_ev = nullptr;
+
+    Comm *comm = nullptr;
+    int rank = 0, world = 1;
+
+    bool is2d() const { return mode == FDTD_MODE_2D_TMZ; }
+    size_t slab_cells() const { return is2d() ? (size_t)nx * sn : (size_t)nx * ny * sn; }
+    int field_comp(int field) const { return field % 3; }
+};
+
+namespace {
+
+template <class T> int dev_alloc(fdtd_ctx *c, T **out, size_t count_with_slack)
+{
+    void *ptr = nullptr;
+    HIPCHK(hipMalloc(&ptr, count_with_slack * sizeof(T)));
+    HIPCHK(hipMemsetAsync(ptr, 0, count_with_slack * sizeof(T), c->stream));
+    c->allocs.push_back(ptr);
+    *out = (T *)ptr;
+    return 0;
+}
+
+int alloc_field(fdtd_ctx *c, float **out)
+{
+    float *base = nullptr;
+    int rc = dev_alloc(c, &base, c->elems + 2 * kSlack);
+    if (rc) return rc;
+    *out = base + kSlack;
+    return 0;
+}
+
+Grid2D grid2d(const fdtd_ctx *c)
+{
+    Grid2D g;
+    const fdtd_params &p = c->p;
+    g.nx = c->nx;
+    g.nyl = c->sn;
+    g.gy0 = c->s0;
+    g.gny = c->gn;
+    g.pitch = c->pitch;
+    g.kh_x = p.dt / (p.mu0 * p.dx);
+    g.kh_y = p.dt / (p.mu0 * p.dy);
+    g.cx = p.dt / p.dx;
+    g.cy = p.dt / p.dy;
+    g.has_lower = c->s0 > 0;
+    return g;
+}
+
+Grid3D grid3d(const fdtd_ctx *c)
+{
+    Grid3D g;
+    const fdtd_params &p = c->p;
+    g.nx = c->nx;
+    g.ny = c->ny;
+    g.nzl = c->sn;
+    g.gz0 = c->s0;
+    g.gnz = c->gn;
+    g.pitch = c->pitch;
+    g.kh_x = p.dt / (p.mu0 * p.dx);
+    g.kh_y = p.dt / (p.mu0 * p.dy);
+    g.kh_z = p.dt / (p.mu0 * p.dz);
+    g.cx = p.dt / p.dx;
+    g.cy = p.dt / p.dy;
+    g.cz = p.dt / p.dz;
+    g.has_lower = c->s0 > 0;
+    return g;
+}
+
+// Sources in global coordinates; the sample index of step n is n - n % 3.
+SourceList sources_for_step(const fdtd_ctx *c)
+{
+    SourceList s = c->src;
+    const int64_t i = c->step - c->step % 3;
+    s.jz = (i >= 0 && i < FDTD_MAX_JZ) ? c->p.jz[i] : 0.0f;
+    return s;
+}
+
+int upload_table(fdtd_ctx *c)
+{
+    std::vector<MatCoef> t(FDTD_MAX_CODES);
+    for (int i = 0; i < FDTD_MAX_CODES; ++i) t[i] = make_coef(c->mats[i], c->p.dt, c->p.eps0, c->ecoef);
+    HIPCHK(hipMemcpyAsync(c->table, t.data(), t.size() * sizeof(MatCoef), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int upload_rp(fdtd_ctx *c, int face)
+{
+    HIPCHK(hipMemcpyAsync(c->rp[face], c->rp_host[face].data(), c->rp_n[face] * sizeof(float),
+                          hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Device address, row pitch and row count of the owned part of a field.
+struct FieldView {
+    float *ptr;
+    size_t rows;
+};
+
+int field_view(fdtd_ctx *c, int field, int level, FieldView *v)
+{
+    if (field < 0 || field >= FDTD_NFIELDS || level < 0 || level > 1) {
+        set_error("bad field id or level");
+        return -3;
+    }
+    const int k = field % 3;
+    float *base;
+    if (field <= FDTD_HZ)
+        base = c->h[k][c->hgen];
+    else if (field <= FDTD_DZ)
+        base = c->d[k][level ? c->cur ^ 1 : c->cur];
+    else
+        base = c->e[k][level ? c->cur ^ 1 : c->cur];
+    if (!base) {
+        set_error("field is not part of the 2-D TMz mode (hx, hy, dz, ez only)");
+        return -3;
+    }
+    if (c->is2d()) {
+        v->ptr = base + (size_t)c->pitch; // skip the lower halo row
+        v->rows = (size_t)c->sn;
+    } else {
+        v->ptr = base + (size_t)c->ny * c->pitch; // skip the lower halo plane
+        v->rows = (size_t)c->sn * c->ny;
+    }
+    return 0;
+}
+
+int upload_codes(fdtd_ctx *c)
+{
+    // owned rows only; halo rows keep the default code (their E is never updated here)
+    const size_t rows = c->is2d() ? (size_t)c->sn : (size_t)c->sn * c->ny;
+    uint8_t *dst = c->code + (c->is2d() ? (size_t)c->pitch : (size_t)c->ny * c->pitch);
+    HIPCHK(hipMemcpy2DAsync(dst, c->pitch, c->codes_host.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice,
+                            c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int use_device(const fdtd_ctx *c)
+{
+    HIPCHK(hipSetDevice(c->device));
+    return 0;
+}
+
+// The rows a neighbour needs / provides.  2-D: one ez row.  3-D: one plane of
+// ex, ey, ez.  Addresses are in the newest E level.
+float *halo_rows(fdtd_ctx *c, int comp, int side, bool halo)
+{
+    float *base = c->e[comp][c->cur];
+    const size_t unit = c->is2d() ? (size_t)c->pitch : (size_t)c->ny * c->pitch;
+    size_t row;
+    if (side == 0)
+        row = halo ? 0 : 1;
+    else
+        row = halo ? (size_t)c->sn + 1 : (size_t)c->sn;
+    return base + row * unit;
+}
+
+int exchange_halos_rccl(fdtd_ctx *c)
+{
+    if (!c->comm || c->world == 1) return 0;
+    const size_t count = c->is2d() ? (size_t)c->nx : (size_t)c->ny * c->pitch;
+    const int c0 = c->is2d() ? 2 : 0;
+    const int lower = c->rank - 1, upper = c->rank + 1;
+    int rc = comm_group_start(c->comm);
+    for (int comp = c0; comp < 3 && rc == 0; ++comp) {
+        if (lower >= 0) {
+            rc = comm_send(c->comm, halo_rows(c, comp, 0, false), count, lower, c->stream);
+            if (rc == 0) rc = comm_recv(c->comm, halo_rows(c, comp, 0, true), count, lower, c->stream);
+        }
+        if (rc == 0 && upper < c->world) {
+            rc = comm_send(c->comm, halo_rows(c, comp, 1, false), count, upper, c->stream);
+            if (rc == 0) rc = comm_recv(c->comm, halo_rows(c, comp, 1, true), count, upper, c->stream);
+        }
+    }
+    int rc2 = comm_group_end(c->comm);
+    return rc ? rc : rc2;
+}
+
+int step_once(fdtd_ctx *c)
+{
+    const bool prof = c->prof_n < c->prof_cap;
+    const int n = c->cur, w = c->cur ^ 1;
+    if (c->is2d()) {
+        Sweep2D a;
+        a.g = grid2d(c);
+        a.ez_n = c->e[2][n];
+        a.ez_w = c->e[2][w];
+        a.dz_n = c->d[2][n];
+        a.dz_w = c->d[2][w];
+        a.code = c->code;
+        a.table = c->table;
+        a.ntab = c->ntab;
+        a.chunk_rows = c->chunk_rows;
+        a.src = sources_for_step(c);
+        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
+        if (c->kernel == FDTD_KERNEL_FUSED) {
+            a.hx_r = c->h[0][c->hgen];
+            a.hy_r = c->h[1][c->hgen];
+            a.hx_w = c->h[0][c->hgen ^ 1];
+            a.hy_w = c->h[1][c->hgen ^ 1];
+            launch_sweep2d(a, c->stream);
+            c->hgen ^= 1;
+        } else {
+            a.hx_r = a.hx_w = c->h[0][c->hgen];
+            a.hy_r = a.hy_w = c->h[1][c->hgen];
+            launch_h2d(a, c->stream);
+            launch_de2d(a, c->stream);
+        }
+        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
+        Mur2D m;
+        m.g = a.g;
+        m.ez_t = c->e[2][w];
+        m.ez_s = c->e[2][n];
+        m.rpx0 = c->rp[FDTD_RP_X0];
+        m.rpxe = c->rp[FDTD_RP_XEND];
+        m.rpy0 = c->rp[FDTD_RP_Y0];
+        m.rpye = c->rp[FDTD_RP_YEND];
+        m.dt = c->p.dt;
+        m.dx = c->p.dx;
+        m.dy = c->p.dy;
+        m.mu0 = c->p.mu0;
+        m.eps0 = c->p.eps0;
+        launch_mur2d(m, c->stream);
+    } else {
+        Sweep3D a;
+        a.g = grid3d(c);
+        for (int k = 0; k < 3; ++k) {
+            a.e_n[k] = c->e[k][n];
+            a.e_w[k] = c->e[k][w];
+            a.d_n[k] = c->d[k][n];
+            a.d_w[k] = c->d[k][w];
+            a.h[k] = c->h[k][c->hgen];
+        }
+        a.code = c->code;
+        a.table = c->table;
+        a.src = sources_for_step(c);
+        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
+        launch_h3d(a, c->stream);
+        launch_de3d(a, c->stream);
+        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
+        Mur3D m;
+        m.g = a.g;
+        for (int k = 0; k < 3; ++k) {
+            m.e_t[k] = c->e[k][w];
+            m.e_s[k] = c->e[k][n];
+        }
+        for (int f = 0; f < 6; ++f) m.rp[f] = c->rp[f];
+        m.dt = c->p.dt;
+        m.dx = c->p.dx;
+        m.dy = c->p.dy;
+        m.dz = c->p.dz;
+        m.mu0 = c->p.mu0;
+        m.eps0 = c->p.eps0;
+        launch_mur3d(m, c->stream);
+    }
+    HIPCHK(hipGetLastError());
+    if (prof) c->prof_n++;
+    c->cur ^= 1;
+    c->step++;
+
+    int rc = exchange_halos_rccl(c);
+    if (rc) return rc;
+
+    if (c->probes.count > 0 && c->probe_ring) {
+        const int slot = (int)((c->step - 1) % c->probe_cap);
+        if (c->is2d()) {
+            Probe2D q;
+            q.g = grid2d(c);
+            q.hx = c->h[0][c->hgen];
+            q.hy = c->h[1][c->hgen];
+            q.dz = c->d[2][c->cur];
+            q.ez = c->e[2][c->cur];
+            q.p = c->probes;
+            q.ring = c->probe_ring;
+            q.slot = slot;
+            launch_probe2d(q, c->stream);
+        } else {
+            Probe3D q;
+            q.g = grid3d(c);
+            for (int k = 0; k < 3; ++k) {
+                q.f[FDTD_HX + k] = c->h[k][c->hgen];
+                q.f[FDTD_DX + k] = c->d[k][c->cur];
+                q.f[FDTD_EX + k] = c->e[k][c->cur];
+            }
+            q.p = c->probes;
+            q.ring = c->probe_ring;
+            q.slot = slot;
+            launch_probe3d(q, c->stream);
+        }
+        if (c->step - c->probe_first > c->probe_cap) c->probe_first = c->step - c->probe_cap;
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+void fdtd_options_default(fdtd_options *opt)
+{
+    std::memset(opt, 0, sizeof *opt);
+    opt->mode = FDTD_MODE_AUTO;
+    opt->ecoef = FDTD_ECOEF_REFERENCE;
+    opt->kernel = FDTD_KERNEL_AUTO;
+}
+
+void fdtd_destroy(fdtd_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->comm) comm_destroy(c->comm);
+    for (void *ptr : c->allocs) (void)hipFree(ptr);
+    if (c->probe_ring) (void)hipFree(c->probe_ring);
+    if (c->snap_dev) (void)hipFree(c->snap_dev);
+    if (c->snap_host) (void)hipHostFree(c->snap_host);
+    if (c->snap_ev) (void)hipEventDestroy(c->snap_ev);
+    for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *c)
+{
+    c->p = *p;
+    c->nx = p->nx;
+    c->ny = p->ny;
+    c->nz = p->nz;
+    c->mode = opt->mode == FDTD_MODE_AUTO ? (p->nz == 1 ? FDTD_MODE_2D_TMZ : FDTD_MODE_3D) : opt->mode;
+    if (c->mode != FDTD_MODE_3D && c->mode != FDTD_MODE_2D_TMZ) {
+        set_error("unknown mode");
+        return -3;
+    }
+    if (c->is2d() && p->nz != 1) {
+        set_error("the 2-D TMz mode needs nz = 1");
+        return -3;
+    }
+    if (p->nx < 3 || p->ny < 3 || (!c->is2d() && p->nz < 3)) {
+        set_error("every extent of the grid must be at least 3");
+        return -3;
+    }
+    if (opt->ecoef != FDTD_ECOEF_REFERENCE && opt->ecoef != FDTD_ECOEF_CONSISTENT) {
+        set_error("unknown ecoef");
+        return -3;
+    }
+    c->ecoef = opt->ecoef;
+    c->kernel = opt->kernel == FDTD_KERNEL_AUTO ? (c->is2d() ? FDTD_KERNEL_FUSED : FDTD_KERNEL_SPLIT) : opt->kernel;
+    if (c->kernel != FDTD_KERNEL_SPLIT && c->kernel != FDTD_KERNEL_FUSED) {
+        set_error("unknown kernel selection");
+        return -3;
+    }
+    if (c->kernel == FDTD_KERNEL_FUSED && !c->is2d()) {
+        set_error("the fused sweep exists for the 2-D TMz mode only");
+        return -3;
+    }
+    c->gn = c->is2d() ? p->ny : p->nz;
+    c->s0 = opt->slab_count > 0 ? opt->slab_begin : 0;
+    c->sn = opt->slab_count > 0 ? opt->slab_count : c->gn;
+    if (c->s0 < 0 || c->sn < 2 || c->s0 + c->sn > c->gn) {
+        set_error("slab must hold at least 2 rows inside the grid");
+        return -3;
+    }
+    c->chunk_rows = opt->chunk_rows > 0 ? opt->chunk_rows : 64;
+    if (p->sources_count < 0 || p->sources_count > FDTD_MAX_SOURCES) {
+        set_error("too many sources");
+        return -3;
+    }
+    c->src.count = p->sources_count;
+    c->src.jz = 0.0f;
+    for (int i = 0; i < p->sources_count; ++i) {
+        const int sx = p->sources[i * 3], sy = p->sources[i * 3 + 1], sz = c->is2d() ? 0 : p->sources[i * 3 + 2];
+        // updateSources reads hy[x-1] and hx[y-1] unguarded (fdtd_calculations.cu:206-207)
+        if (sx < 1 || sx > p->nx - 1 || sy < 1 || sy > p->ny - 1 || sz < 0 || sz > p->nz - 1) {
+            set_error("source_location outside 2..nx, 2..ny, 1..nz");
+            return -3;
+        }
+        c->src.x[i] = sx;
+        c->src.y[i] = sy;
+        c->src.z[i] = sz;
+    }
+
+    c->device = opt->device;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->snap_ev, hipEventDisableTiming));
+
+    int skew = 0;
+    if (const char *s = std::getenv("FDTD_PITCH_SKEW")) skew = std::atoi(s);
+    c->pitch = (c->nx + 63) / 64 * 64 + skew * 64;
+    c->rows_store = c->is2d() ? (size_t)c->sn + 2 : ((size_t)c->sn + 2) * c->ny;
+    c->elems = c->rows_store * c->pitch;
+
+    int rc = 0;
+    const bool two_h = c->kernel == FDTD_KERNEL_FUSED;
+    for (int k = 0; k < 3 && !rc; ++k) {
+        const bool used_h = c->is2d() ? k < 2 : true;  // hx, hy
+        const bool used_ed = c->is2d() ? k == 2 : true; // dz, ez
+        if (used_h) {
+            rc = alloc_field(c, &c->h[k][0]);
+            if (!rc && two_h) rc = alloc_field(c, &c->h[k][1]);
+        }
+        for (int l = 0; l < 2 && used_ed && !rc; ++l) {
+            rc = alloc_field(c, &c->e[k][l]);
+            if (!rc) rc = alloc_field(c, &c->d[k][l]);
+        }
+    }
+    if (rc) return rc;
+    uint8_t *code_base = nullptr;
+    if ((rc = dev_alloc(c, &code_base, c->elems + 2 * kSlack))) return rc;
+    c->code = code_base + kSlack;
+    launch_fill_u8(code_base, c->elems + 2 * kSlack, (uint8_t)kDefaultCode, c->stream);
+    if ((rc = dev_alloc(c, &c->table, (size_t)FDTD_MAX_CODES))) return rc;
+
+    // Every code maps to the defaults until a spec table is loaded.
+    const MaterialRow def = {p->default_sigma, p->default_eps_s, p->default_eps_i, p->default_tau_d};
+    for (int i = 0; i < FDTD_MAX_CODES; ++i) c->mats[i] = def;
+    if ((rc = upload_table(c))) return rc;
+
+    // setupMurBoundary on the defaults (fdtd.cu:59 runs before :65).
+    const size_t gy = (size_t)p->ny, gz = (size_t)p->nz, gx = (size_t)p->nx;
+    c->rp_n[FDTD_RP_X0] = c->rp_n[FDTD_RP_XEND] = 2 * gy * gz;
+    c->rp_n[FDTD_RP_Y0] = c->rp_n[FDTD_RP_YEND] = gx * 2 * gz;
+    c->rp_n[FDTD_RP_Z0] = c->rp_n[FDTD_RP_ZEND] = gx * gy * 2;
+    const float rx = rp_value(*p, def, true), ryz = rp_value(*p, def, false);
+    for (int f = 0; f < 6; ++f) {
+        c->rp_host[f].assign(c->rp_n[f], (f % 3 == 0) ? rx : ryz);
+        if ((rc = dev_alloc(c, &c->rp[f], c->rp_n[f]))) return rc;
+        if ((rc = upload_rp(c, f))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fdtd_create(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx **out)
+{
+    if (!p || !out) {
+        set_error("fdtd_create: null argument");
+        return -3;
+    }
+    fdtd_options o;
+    if (opt)
+        o = *opt;
+    else
+        fdtd_options_default(&o);
+    fdtd_ctx *c = new fdtd_ctx();
+    int rc = create_impl(p, &o, c);
+    if (rc) {
+        const std::string keep = fdtd_last_error();
+        fdtd_destroy(c);
+        set_error(keep);
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+
+int fdtd_set_material(fdtd_ctx *c, int code, float sigma, float eps_s, float eps_inf, float tau_d)
+{
+    if (code < 0 || code >= FDTD_MAX_CODES) {
+        set_error("material code out of range 0..255");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    c->mats[code] = {sigma, eps_s, eps_inf, tau_d};
+    return upload_table(c);
+}
+
+int fdtd_set_codes(fdtd_ctx *c, const uint8_t *codes, size_t count)
+{
+    if (count != c->slab_cells()) {
+        set_error("fdtd_set_codes: count must be the number of cells of the slab");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    c->codes_host.assign(codes, codes + count);
+    return upload_codes(c);
+}
+
+int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir, int first_slice, int upsample)
+{
+    if (use_device(c)) return -10;
+    bool present[FDTD_MAX_CODES] = {};
+    MaterialRow table[FDTD_MAX_CODES];
+    // codes without a row in the spec file get zeros, as calloc gives them (fdtd.cu:879)
+    std::memset(table, 0, sizeof table);
+    int rc = read_material_specs(specs_path, table, present);
+    if (rc) return rc;
+    const MaterialRow def = c->mats[kDefaultCode];
+    for (int i = 0; i < FDTD_MAX_CODES; ++i) c->mats[i] = table[i];
+    c->mats[kDefaultCode] = def;
+
+    c->codes_host.assign(c->slab_cells(), 0);
+    if (c->is2d()) {
+        char path[2048];
+        std::snprintf(path, sizeof path, "%s/v1_%05d.pgm", pgm_dir, first_slice);
+        rc = read_pgm_slice(path, c->nx, c->ny, upsample, c->s0, c->sn, c->codes_host.data());
+        if (rc) return rc;
+    } else {
+        for (int k = 0; k < c->sn; ++k) {
+            char path[2048];
+            std::snprintf(path, sizeof path, "%s/v1_%05d.pgm", pgm_dir, c->s0 + k + first_slice);
+            rc = read_pgm_slice(path, c->nx, c->ny, upsample, 0, c->ny,
+                                c->codes_host.data() + (size_t)k * c->nx * c->ny);
+            if (rc) return rc;
+        }
+    }
+    if ((rc = upload_table(c))) return rc;
+    return upload_codes(c);
+}
+
+int fdtd_set_rp(fdtd_ctx *c, int face, const float *data, size_t count)
+{
+    if (face < 0 || face > 5 || count != c->rp_n[face]) {
+        set_error("fdtd_set_rp: bad face or count");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    c->rp_host[face].assign(data, data + count);
+    return upload_rp(c, face);
+}
+
+int fdtd_get_rp(fdtd_ctx *c, int face, float *data, size_t count)
+{
+    if (face < 0 || face > 5 || count != c->rp_n[face]) {
+        set_error("fdtd_get_rp: bad face or count");
+        return -3;
+    }
+    std::memcpy(data, c->rp_host[face].data(), count * sizeof(float));
+    return 0;
+}
+
+int fdtd_setup_mur_from_materials(fdtd_ctx *c)
+{
+    if (c->sn != c->gn) {
+        set_error("fdtd_setup_mur_from_materials needs the whole grid in one slab");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    const int nx = c->nx, ny = c->ny, nz = c->nz;
+    auto mat = [&](int x, int y, int z) -> const MaterialRow & {
+        if (c->codes_host.empty()) return c->mats[kDefaultCode];
+        return c->mats[c->codes_host[((size_t)z * ny + y) * nx + x]];
+    };
+    for (int z = 0; z < nz; ++z)
+        for (int y = 0; y < ny; ++y)
+            for (int k = 0; k < 2; ++k) {
+                const size_t r = ((size_t)z * ny + y) * 2 + k;
+                c->rp_host[FDTD_RP_X0][r] = rp_value(c->p, mat(k, y, z), true);
+                c->rp_host[FDTD_RP_XEND][r] = rp_value(c->p, mat(nx - 2 + k, y, z), true);
+            }
+    for (int z = 0; z < nz; ++z)
+        for (int k = 0; k < 2; ++k)
+            for (int x = 0; x < nx; ++x) {
+                const size_t r = ((size_t)z * 2 + k) * nx + x;
+                c->rp_host[FDTD_RP_Y0][r] = rp_value(c->p, mat(x, k, z), false);
+                c->rp_host[FDTD_RP_YEND][r] = rp_value(c->p, mat(x, ny - 2 + k, z), false);
+            }
+    if (!c->is2d())
+        for (int k = 0; k < 2; ++k)
+            for (int y = 0; y < ny; ++y)
+                for (int x = 0; x < nx; ++x) {
+                    const size_t r = ((size_t)k * ny + y) * nx + x;
+                    c->rp_host[FDTD_RP_Z0][r] = rp_value(c->p, mat(x, y, k), false);
+                    c->rp_host[FDTD_RP_ZEND][r] = rp_value(c->p, mat(x, y, nz - 2 + k), false);
+                }
+    for (int f = 0; f < 6; ++f) {
+        int rc = upload_rp(c, f);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int fdtd_step(fdtd_ctx *c, int nsteps)
+{
+    if (use_device(c)) return -10;
+    for (int i = 0; i < nsteps; ++i) {
+        int rc = step_once(c);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int fdtd_sync(fdtd_ctx *c)
+{
+    if (use_device(c)) return -10;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int64_t fdtd_steps_done(const fdtd_ctx *c) { return c->step; }
+
+int fdtd_profile_begin(fdtd_ctx *c, int capacity)
+{
+    if (use_device(c)) return -10;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    while ((int)c->prof_ev.size() < 2 * capacity) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreate(&ev));
+        c->prof_ev.push_back(ev);
+    }
+    c->prof_cap = capacity;
+    c->prof_n = 0;
+    return 0;
+}
+
+int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
+{
+    if (use_device(c)) return -10;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const int n = std::min(capacity, c->prof_n);
+    for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&sweep_ms[i], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    if (count) *count = n;
+    c->prof_cap = 0;
+    return 0;
+}
+
+const char *fdtd_sweep_kernel_name(const fdtd_ctx *c)
+{
+    if (c->is2d()) return c->kernel == FDTD_KERNEL_FUSED ? sweep2d_kernel_name() : de2d_kernel_name();
+    return de3d_kernel_name();
+}
+
+int fdtd_read_field(fdtd_ctx *c, int field, int level, float *dst, size_t count)
+{
+    if (use_device(c)) return -10;
+    FieldView v;
+    int rc = field_view(c, field, level, &v);
+    if (rc) return rc;
+    if (count != v.rows * c->nx) {
+        set_error("fdtd_read_field: count must be the number of cells of the slab");
+        return -3;
+    }
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)c->nx * 4, v.ptr, (size_t)c->pitch * 4, (size_t)c->nx * 4, v.rows,
+                            hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fdtd_write_field(fdtd_ctx *c, int field, int level, const float *src, size_t count)
+{
+    if (use_device(c)) return -10;
+    FieldView v;
+    int rc = field_view(c, field, level, &v);
+    if (rc) return rc;
+    if (count != v.rows * c->nx) {
+        set_error("fdtd_write_field: count must be the number of cells of the slab");
+        return -3;
+    }
+    HIPCHK(hipMemcpy2DAsync(v.ptr, (size_t)c->pitch * 4, src, (size_t)c->nx * 4, (size_t)c->nx * 4, v.rows,
+                            hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fdtd_snapshot_wait(fdtd_ctx *c)
+{
+    if (!c->snap_pending) return 0;
+    if (use_device(c)) return -10;
+    HIPCHK(hipStreamSynchronize(c->side));
+    std::memcpy(c->snap_dst, c->snap_host, c->snap_count * sizeof(float));
+    c->snap_pending = false;
+    return 0;
+}
+
+int fdtd_snapshot_async(fdtd_ctx *c, int field, float *dst, size_t count)
+{
+    if (use_device(c)) return -10;
+    int rc = fdtd_snapshot_wait(c);
+    if (rc) return rc;
+    FieldView v;
+    if ((rc = field_view(c, field, 0, &v))) return rc;
+    if (count != v.rows * c->nx) {
+        set_error("fdtd_snapshot_async: count must be the number of cells of the slab");
+        return -3;
+    }
+    if (c->snap_count != count) {
+        if (c->snap_dev) (void)hipFree(c->snap_dev);
+        if (c->snap_host) (void)hipHostFree(c->snap_host);
+        c->snap_dev = nullptr;
+        c->snap_host = nullptr;
+        c->snap_count = 0;
+        HIPCHK(hipMalloc((void **)&c->snap_dev, count * sizeof(float)));
+        HIPCHK(hipHostMalloc((void **)&c->snap_host, count * sizeof(float), hipHostMallocDefault));
+        c->snap_count = count;
+    }
+    // compact device copy on the compute stream (later steps may overwrite the
+    // field), then the slow D2H on the side stream
+    HIPCHK(hipMemcpy2DAsync(c->snap_dev, (size_t)c->nx * 4, v.ptr, (size_t)c->pitch * 4, (size_t)c->nx * 4, v.rows,
+                            hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(hipEventRecord(c->snap_ev, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->side, c->snap_ev, 0));
+    HIPCHK(hipMemcpyAsync(c->snap_host, c->snap_dev, count * sizeof(float), hipMemcpyDeviceToHost, c->side));
+    c->snap_dst = dst;
+    c->snap_pending = true;
+    return 0;
+}
+
+int fdtd_probe_fields(const fdtd_ctx *c) { return c->is2d() ? 4 : 9; }
+
+int fdtd_set_probes(fdtd_ctx *c, int count, const int32_t *xyz, int capacity)
+{
+    if (count < 0 || count > FDTD_MAX_PROBES || capacity < 1) {
+        set_error("fdtd_set_probes: 0..16 probes, capacity >= 1");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->probe_ring) (void)hipFree(c->probe_ring);
+    c->probe_ring = nullptr;
+    c->probes.count = count;
+    for (int i = 0; i < count; ++i) {
+        c->probes.x[i] = xyz[i * 3];
+        c->probes.y[i] = xyz[i * 3 + 1];
+        c->probes.z[i] = c->is2d() ? 0 : xyz[i * 3 + 2];
+    }
+    c->probe_cap = capacity;
+    c->probe_first = c->step;
+    const size_t n = (size_t)capacity * FDTD_MAX_PROBES * fdtd_probe_fields(c);
+    HIPCHK(hipMalloc((void **)&c->probe_ring, n * sizeof(float)));
+    HIPCHK(hipMemsetAsync(c->probe_ring, 0, n * sizeof(float), c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fdtd_read_probes(fdtd_ctx *c, int64_t first_step, int nsteps, float *dst, size_t count)
+{
+    if (use_device(c)) return -10;
+    const int nf = fdtd_probe_fields(c), np = c->probes.count;
+    if (!c->probe_ring || first_step < c->probe_first || first_step + nsteps > c->step ||
+        count != (size_t)nsteps * np * nf) {
+        set_error("fdtd_read_probes: rows not in the ring, or wrong count");
+        return -3;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t row = (size_t)FDTD_MAX_PROBES * nf;
+    std::vector<float> tmp(row);
+    for (int s = 0; s < nsteps; ++s) {
+        const int slot = (int)((first_step + s) % c->probe_cap);
+        HIPCHK(hipMemcpy(tmp.data(), c->probe_ring + (size_t)slot * row, row * sizeof(float), hipMemcpyDeviceToHost));
+        std::memcpy(dst + (size_t)s * np * nf, tmp.data(), (size_t)np * nf * sizeof(float));
+    }
+    return 0;
+}
+
+size_t fdtd_halo_count(const fdtd_ctx *c) { return c->is2d() ? (size_t)c->nx : (size_t)3 * c->nx * c->ny; }
+
+static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get)
+{
+    if (side < 0 || side > 1 || count != fdtd_halo_count(c)) {
+        set_error("halo: bad side or count");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    const int c0 = c->is2d() ? 2 : 0;
+    const size_t rows = c->is2d() ? 1 : (size_t)c->ny;
+    for (int comp = c0; comp < 3; ++comp) {
+        float *dev = halo_rows(c, comp, side, !get);
+        float *h = host + (size_t)(comp - c0) * c->nx * rows;
+        if (get)
+            HIPCHK(hipMemcpy2DAsync(h, (size_t)c->nx * 4, dev, (size_t)c->pitch * 4, (size_t)c->nx * 4, rows,
+                                    hipMemcpyDeviceToHost, c->stream));
+        else
+            HIPCHK(hipMemcpy2DAsync(dev, (size_t)c->pitch * 4, h, (size_t)c->nx * 4, (size_t)c->nx * 4, rows,
+                                    hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int fdtd_halo_get(fdtd_ctx *c, int side, float *dst, size_t count) { return halo_copy(c, side, dst, count, true); }
+int fdtd_halo_put(fdtd_ctx *c, int side, const float *src, size_t count)
+{
+    return halo_copy(c, side, const_cast<float *>(src), count, false);
+}
+
+int fdtd_comm_unique_id(char id[128]) { return comm_unique_id(id); }
+
+int fdtd_comm_init(fdtd_ctx *c, const char id[128], int rank, int world)
+{
+    if (world < 1 || rank < 0 || rank >= world) {
+        set_error("fdtd_comm_init: bad rank/world");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    if (c->comm) {
+        comm_destroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->rank = rank;
+    c->world = world;
+    if (world == 1) return 0;
+    return comm_create(id, rank, world, &c->comm);
+}
+
+} // extern "C"

@@ -1,0 +1,150 @@
+// Internal declarations shared by the host code and the HIP kernels of
+// libfdtd_amd.so.  Nothing here is part of the C ABI (include/fdtd_amd.h).
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "fdtd_amd.h"
+
+namespace fdtd {
+
+// Material code that stands for the fsigma/feps_s/feps_inf/ftau_d defaults of
+// data/input_params (every cell holds it until materials are loaded).
+constexpr int kDefaultCode = 255;
+
+// Debye E-update coefficients of one material (fdtd_calculations.cu:141-156),
+// evaluated once per material code instead of once per cell per step.  The
+// values depend only on (sigma, eps_s, eps_inf, tau_d, dt, eps0), so a table
+// row is bit-identical to what the reference recomputes in every thread.
+struct alignas(16) MatCoef {
+    float a, c, d, pad0;
+    double k1, k2;   // 2(dt + tau), 2dt + 4tau
+    double k3, pad1; // 2tau
+};
+static_assert(sizeof(MatCoef) == 48, "MatCoef is read as three 16-byte LDS words");
+
+struct MaterialRow {
+    float sigma, eps_s, eps_inf, tau_d;
+};
+
+struct SourceList {
+    int count;
+    int x[FDTD_MAX_SOURCES], y[FDTD_MAX_SOURCES], z[FDTD_MAX_SOURCES];
+    float jz; // sample of this step: jz[n - n % 3] (fdtd.cu:172,310,448), 0 past the table
+};
+
+struct ProbeList {
+    int count;
+    int x[FDTD_MAX_PROBES], y[FDTD_MAX_PROBES], z[FDTD_MAX_PROBES];
+};
+
+// ---- 2-D TMz ----------------------------------------------------------
+// Storage: (nyl + 2) rows of `pitch` floats per array; storage row r holds
+// local row j = r - 1, i.e. global row gy0 + j; rows j = -1 and j = nyl are
+// halo rows (zero outside the grid).  Every pointer addresses storage row 0.
+struct Grid2D {
+    int nx, nyl, gy0, gny, pitch;
+    float kh_x, kh_y; // dt/(mu0*dx), dt/(mu0*dy)   (fdtd_calculations.cu:49,63)
+    float cx, cy;     // dt/dx, dt/dy               (fdtd_calculations.cu:92-93)
+    int has_lower;    // a neighbour slab exists below (gy0 > 0)
+};
+
+struct Sweep2D {
+    Grid2D g;
+    const float *ez_n;  // E level n
+    float *ez_w;        // holds level n-1, receives n+1
+    const float *dz_n;
+    float *dz_w;
+    const float *hx_r, *hy_r; // H read generation
+    float *hx_w, *hy_w;       // H write generation (== read generation for the split kernels)
+    const uint8_t *code;
+    const MatCoef *table;
+    int ntab;
+    int chunk_rows;
+    SourceList src;
+};
+
+struct Mur2D {
+    Grid2D g;
+    float *ez_t;       // level n+1
+    const float *ez_s; // level n
+    const float *rpx0, *rpxe, *rpy0, *rpye; // global layouts of fdtd.cu:952-977
+    float dt, dx, dy, mu0, eps0;
+};
+
+// ---- 3-D ----------------------------------------------------------------
+// Storage: (nzl + 2) planes of ny rows of `pitch` floats; storage plane q holds
+// local plane k = q - 1 (global gz0 + k); planes k = -1 and k = nzl are halos.
+struct Grid3D {
+    int nx, ny, nzl, gz0, gnz, pitch;
+    float kh_x, kh_y, kh_z;
+    float cx, cy, cz;
+    int has_lower;
+};
+
+struct Sweep3D {
+    Grid3D g;
+    const float *e_n[3];
+    float *e_w[3];
+    const float *d_n[3];
+    float *d_w[3];
+    float *h[3];
+    const uint8_t *code;
+    const MatCoef *table;
+    SourceList src;
+};
+
+struct Mur3D {
+    Grid3D g;
+    float *e_t[3];
+    const float *e_s[3];
+    const float *rp[6];
+    float dt, dx, dy, dz, mu0, eps0;
+};
+
+struct Probe2D {
+    Grid2D g;
+    const float *hx, *hy, *dz, *ez;
+    ProbeList p;
+    float *ring;
+    int slot;
+};
+
+struct Probe3D {
+    Grid3D g;
+    const float *f[9];
+    ProbeList p;
+    float *ring;
+    int slot;
+};
+
+// Kernel launchers (kernels.hip).  `stream` is a hipStream_t.
+void launch_h2d(const Sweep2D &a, void *stream);
+void launch_de2d(const Sweep2D &a, void *stream);
+void launch_sweep2d(const Sweep2D &a, void *stream);
+void launch_mur2d(const Mur2D &a, void *stream);
+void launch_h3d(const Sweep3D &a, void *stream);
+void launch_de3d(const Sweep3D &a, void *stream);
+void launch_mur3d(const Mur3D &a, void *stream);
+void launch_probe2d(const Probe2D &a, void *stream);
+void launch_probe3d(const Probe3D &a, void *stream);
+void launch_fill_u8(uint8_t *p, size_t n, uint8_t v, void *stream);
+const char *sweep2d_kernel_name();
+const char *de3d_kernel_name();
+const char *de2d_kernel_name();
+
+// Host-side set-up (host_setup.cpp).
+void set_error(const std::string &msg);
+int params_load(const char *path, fdtd_params *out);
+void params_derive(fdtd_params *p);
+int setup_sources(fdtd_params *p);
+MatCoef make_coef(const MaterialRow &m, float dt, float eps0, int ecoef);
+float rp_value(const fdtd_params &p, const MaterialRow &m, bool x_face);
+int read_material_specs(const char *path, MaterialRow table[FDTD_MAX_CODES], bool present[FDTD_MAX_CODES]);
+// Codes of one z slice for rows [y0, y0 + rows) of an nx-wide grid.
+int read_pgm_slice(const char *path, int nx, int ny, int upsample, int y0, int rows, uint8_t *dst);
+
+} // namespace fdtd

@@ -1,0 +1,523 @@
+// HIP kernels of the FDTD field-update path for gfx950 (MI355X).
+//
+// What each kernel replaces in the reference (UnalignedByte/fdtd):
+//   fdtd2d_sweep : updateHField + updateDField + updateSources + updateEField
+//                  (fdtd_calculations.cu:32-213) for the 2-D TMz reduction, one
+//                  pass over memory per time step
+//   fdtd2d_h, fdtd2d_de, fdtd3d_h, fdtd3d_de : the same equations as an H
+//                  kernel and a fused D+source+E kernel
+//   fdtd2d_mur, fdtd3d_mur : updateMurBoundary (fdtd_calculations.cu:216-428)
+//
+// Arithmetic keeps the reference's evaluation order and its fp32/fp64 mix and
+// is compiled with -ffp-contract=off, so results are bit-comparable with a
+// host build of the same equations.  The kernels are bandwidth bound (about
+// 0.5 flop per byte): no MFMA, wide coalesced loads, neighbours through lane
+// shuffles, the material table in LDS.
+#include <hip/hip_runtime.h>
+
+#include "internal.h"
+
+namespace fdtd {
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// E^{n+1} of one cell, fdtd_calculations.cu:150-156:
+//   c * ( d*E^n - a*E^{n-1}  [fp32]  + 2(dt+tau)*D^{n+1} - (2dt+4tau)*D^n + 2tau*D^{n-1}  [fp64] )
+__device__ __forceinline__ float e_update(const MatCoef &m, float e0, float e1, float d0, float d1,
+                                          float d2)
+{
+    const float f = m.d * e0 - m.a * e1;
+    double acc = (double)f + m.k1 * (double)d0;
+    acc = acc - m.k2 * (double)d1;
+    acc = acc + m.k3 * (double)d2;
+    return (float)((double)m.c * acc);
+}
+
+// First-order Mur face value, fdtd_calculations.cu:240-248 and its siblings.
+// r_here: rp on the face layer, r_in: rp on the first interior layer.
+__device__ __forceinline__ float mur_face(float dt, float du, float mu0, float eps0, float r_here,
+                                          float r_in, float et_in, float es_in, float es_here)
+{
+    const float s_here = du * sqrtf(mu0 * eps0 * r_here);
+    const float s_in = du * sqrtf(mu0 * eps0 * r_in);
+    return 1.0f / (dt + s_here) * ((dt - s_in) * et_in + (dt + s_in) * es_in - (dt - s_here) * es_here);
+}
+
+__device__ __forceinline__ bool is_source2d(const SourceList &s, int x, int gy)
+{
+    bool hit = false;
+    for (int i = 0; i < s.count; ++i) hit |= (s.x[i] == x) & (s.y[i] == gy);
+    return hit;
+}
+
+__device__ __forceinline__ bool is_source3d(const SourceList &s, int x, int y, int gz)
+{
+    bool hit = false;
+    for (int i = 0; i < s.count; ++i) hit |= (s.x[i] == x) & (s.y[i] == y) & (s.z[i] == gz);
+    return hit;
+}
+
+// ------------------------------------------------------------------ 2-D split
+
+// H update in place, one thread per cell.  blockIdx.y walks storage rows
+// starting at the lower halo row when a neighbour slab exists: its hx row is
+// recomputed here every step so that only ez has to be exchanged.
+__global__ __launch_bounds__(256) void fdtd2d_h(const Sweep2D a)
+{
+    const Grid2D &g = a.g;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int j = (int)blockIdx.y - g.has_lower;
+    if (x >= g.nx) return;
+    const int y = g.gy0 + j;
+    const size_t o = (size_t)(j + 1) * g.pitch + x;
+    if (x >= 1 && x <= g.nx - 2 && y >= 0 && y <= g.gny - 2)
+        a.hx_w[o] = a.hx_r[o] - g.kh_y * (a.ez_n[o + g.pitch] - a.ez_n[o]);
+    if (j >= 0 && x <= g.nx - 2 && y >= 1 && y <= g.gny - 2)
+        a.hy_w[o] = a.hy_r[o] + g.kh_x * (a.ez_n[o + 1] - a.ez_n[o]);
+}
+
+// D + source + E, one thread per cell of the owned rows.
+__global__ __launch_bounds__(256) void fdtd2d_de(const Sweep2D a)
+{
+    const Grid2D &g = a.g;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.y;
+    if (x >= g.nx) return;
+    const int y = g.gy0 + j;
+    const size_t o = (size_t)(j + 1) * g.pitch + x;
+    const float d0 = a.dz_n[o];
+    const float d1 = a.dz_w[o];
+    float dn = d1;
+    const bool guard = x >= 1 && x <= g.nx - 2 && y >= 1 && y <= g.gny - 2;
+    const bool src = is_source2d(a.src, x, y);
+    if (guard || src) {
+        const float v = (d0 + g.cx * (a.hy_r[o] - a.hy_r[o - 1])) - g.cy * (a.hx_r[o] - a.hx_r[o - g.pitch]);
+        dn = src ? v - a.src.jz : v;
+        a.dz_w[o] = dn;
+    }
+    if (x >= 1) {
+        const MatCoef m = a.table[a.code[o]];
+        a.ez_w[o] = e_update(m, a.ez_n[o], a.ez_w[o], dn, d0, d1);
+    }
+}
+
+// ------------------------------------------------------------------ 2-D fused
+//
+// One pass per time step.  A wave owns a strip of 256 columns (lane l holds
+// columns 4l..4l+3 as one 16-byte word per array) and marches `chunk_rows`
+// rows in y.  The row above (ez^n) and the previous row's new hx stay in
+// registers, x neighbours come from the adjacent lane, and the two strip-edge
+// values (ez^n to the right, new hy to the left) are fetched or recomputed by
+// the edge lanes.  H is read from one generation and written to the other, so
+// recomputing a neighbour's H value never races with that neighbour's store.
+// Per cell this moves hx, hy, ez^n, ez^{n-1}, dz^n, dz^{n-1} (24 B) + 1 B code
+// in and hx, hy, ez^{n+1}, dz^{n+1} (16 B) out.
+__global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a)
+{
+    __shared__ MatCoef tab[FDTD_MAX_CODES];
+    for (int i = threadIdx.x; i < a.ntab; i += 256) tab[i] = a.table[i];
+    __syncthreads();
+
+    const Grid2D &g = a.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int xw0 = ((int)blockIdx.x * 4 + wave) * 256;
+    if (xw0 >= g.nx) return;
+    const int x4 = xw0 + lane * 4;
+    const bool act = x4 < g.nx;
+    const int j0 = (int)blockIdx.y * a.chunk_rows;
+    const int j1 = min(j0 + a.chunk_rows, g.nyl);
+    const size_t pitch = (size_t)g.pitch;
+
+    // x guards of the four columns held by this lane
+    bool m_hx[4], m_hy[4], m_ez[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = x4 + i;
+        m_hx[i] = x >= 1 && x <= g.nx - 2;          // also the dz guard
+        m_hy[i] = x <= g.nx - 2;
+        m_ez[i] = x >= 1 && x <= g.nx - 1;
+    }
+    const bool edge_r = (lane == 63) && (xw0 + 256 < g.nx);
+    const bool edge_l = (lane == 0) && (xw0 > 0);
+
+    // sources that fall into this wave's strip and rows (wave-uniform mask)
+    unsigned srcmask = 0;
+    for (int s = 0; s < a.src.count; ++s) {
+        const int js = a.src.y[s] - g.gy0;
+        if (a.src.x[s] >= xw0 && a.src.x[s] < xw0 + 256 && js >= j0 && js < j1) srcmask |= 1u << s;
+    }
+
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    size_t off = (size_t)(j0 + 1) * pitch + x4;
+
+    // Prologue: new hx of row j0 - 1 (owned by the chunk below, or the halo row).
+    f4 ezc = act ? *(const f4 *)(a.ez_n + off) : zero;
+    f4 hxp = act ? *(const f4 *)(a.hx_r + off - pitch) : zero;
+    {
+        const f4 ezm = act ? *(const f4 *)(a.ez_n + off - pitch) : zero;
+        const int y = g.gy0 + j0 - 1;
+        if (y >= 0 && y <= g.gny - 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m_hx[i]) hxp[i] = hxp[i] - g.kh_y * (ezc[i] - ezm[i]);
+        }
+        if (j0 == 0 && g.has_lower && act) *(f4 *)(a.hx_w + off - pitch) = hxp;
+    }
+
+    for (int j = j0; j < j1; ++j, off += pitch) {
+        const int y = g.gy0 + j;
+        const f4 ezn = act ? *(const f4 *)(a.ez_n + off + pitch) : zero;
+        const f4 hxo = act ? *(const f4 *)(a.hx_r + off) : zero;
+        const f4 hyo = act ? *(const f4 *)(a.hy_r + off) : zero;
+        const f4 e1 = act ? *(const f4 *)(a.ez_w + off) : zero;
+        const f4 d0 = act ? *(const f4 *)(a.dz_n + off) : zero;
+        const f4 d1 = act ? *(const f4 *)(a.dz_w + off) : zero;
+        const unsigned cd = act ? *(const unsigned *)(a.code + off) : 0u;
+
+        float e_right = __shfl_down(ezc.x, 1);
+        if (lane == 63) e_right = edge_r ? a.ez_n[off + 4] : 0.f;
+        float hy_lo = 0.f, ez_lo = 0.f;
+        if (edge_l) {
+            hy_lo = a.hy_r[off - 1];
+            ez_lo = a.ez_n[off - 1];
+        }
+
+        const bool gy_hx = y <= g.gny - 2;
+        const bool gy_in = y >= 1 && y <= g.gny - 2;
+
+        f4 hxn, hyn;
+        const float er[4] = {ezc.y, ezc.z, ezc.w, e_right};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            hxn[i] = (gy_hx && m_hx[i]) ? hxo[i] - g.kh_y * (ezn[i] - ezc[i]) : hxo[i];
+            hyn[i] = (gy_in && m_hy[i]) ? hyo[i] + g.kh_x * (er[i] - ezc[i]) : hyo[i];
+        }
+        float hy_left = __shfl_up(hyn.w, 1);
+        if (lane == 0) hy_left = (edge_l && gy_in) ? hy_lo + g.kh_x * (ezc.x - ez_lo) : hy_lo;
+        const float hl[4] = {hy_left, hyn.x, hyn.y, hyn.z};
+
+        unsigned srcflag = 0;
+        if (srcmask) {
+            for (int s = 0; s < a.src.count; ++s) {
+                if (!((srcmask >> s) & 1u) || a.src.y[s] - g.gy0 != j) continue;
+                const int rel = a.src.x[s] - xw0;
+                if ((rel >> 2) == lane) srcflag |= 1u << (rel & 3);
+            }
+        }
+
+        f4 dzn, ezw;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = (d0[i] + g.cx * (hyn[i] - hl[i])) - g.cy * (hxn[i] - hxp[i]);
+            float dn = (gy_in && m_hx[i]) ? v : d1[i];
+            if ((srcflag >> i) & 1u) dn = v - a.src.jz;
+            dzn[i] = dn;
+            const MatCoef &m = tab[(cd >> (8 * i)) & 0xffu];
+            ezw[i] = m_ez[i] ? e_update(m, ezc[i], e1[i], dn, d0[i], d1[i]) : e1[i];
+        }
+
+        if (act) {
+            *(f4 *)(a.hx_w + off) = hxn;
+            *(f4 *)(a.hy_w + off) = hyn;
+            *(f4 *)(a.dz_w + off) = dzn;
+            *(f4 *)(a.ez_w + off) = ezw;
+        }
+        hxp = hxn;
+        ezc = ezn;
+    }
+}
+
+// ez on the four edges, fdtd_calculations.cu:369-427 with iz = 0.
+__global__ __launch_bounds__(256) void fdtd2d_mur(const Mur2D a)
+{
+    const Grid2D &g = a.g;
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const size_t pitch = (size_t)g.pitch;
+    if (t < 2L * g.nyl) {
+        const int side = (int)(t / g.nyl), j = (int)(t % g.nyl);
+        const int y = g.gy0 + j;
+        if (y < 1 || y > g.gny - 2) return;
+        const size_t row = (size_t)(j + 1) * pitch;
+        if (side == 0) {
+            const size_t f = row, in = row + 1;
+            a.ez_t[f] = mur_face(a.dt, a.dx, a.mu0, a.eps0, a.rpx0[(size_t)y * 2], a.rpx0[(size_t)y * 2 + 1],
+                                 a.ez_t[in], a.ez_s[in], a.ez_s[f]);
+        } else {
+            const size_t f = row + g.nx - 1, in = row + g.nx - 2;
+            a.ez_t[f] = mur_face(a.dt, a.dx, a.mu0, a.eps0, a.rpxe[(size_t)y * 2 + 1], a.rpxe[(size_t)y * 2],
+                                 a.ez_t[in], a.ez_s[in], a.ez_s[f]);
+        }
+        return;
+    }
+    t -= 2L * g.nyl;
+    if (t >= 2L * g.nx) return;
+    const int side = (int)(t / g.nx), x = (int)(t % g.nx);
+    if (x < 1 || x > g.nx - 2) return;
+    if (side == 0) {
+        if (g.gy0 != 0) return;
+        const size_t f = pitch + x, in = 2 * pitch + x;
+        a.ez_t[f] = mur_face(a.dt, a.dy, a.mu0, a.eps0, a.rpy0[x], a.rpy0[g.nx + x], a.ez_t[in], a.ez_s[in],
+                             a.ez_s[f]);
+    } else {
+        if (g.gy0 + g.nyl != g.gny) return;
+        const size_t f = (size_t)g.nyl * pitch + x, in = (size_t)(g.nyl - 1) * pitch + x;
+        a.ez_t[f] = mur_face(a.dt, a.dy, a.mu0, a.eps0, a.rpye[g.nx + x], a.rpye[x], a.ez_t[in], a.ez_s[in],
+                             a.ez_s[f]);
+    }
+}
+
+// ------------------------------------------------------------------ 3-D split
+
+// updateHField, fdtd_calculations.cu:32-77 (in place).  blockIdx.z starts at
+// the lower halo plane when a neighbour slab exists (hx, hy only).
+__global__ __launch_bounds__(256) void fdtd3d_h(const Sweep3D a)
+{
+    const Grid3D &g = a.g;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int k = (int)blockIdx.z - g.has_lower;
+    if (x >= g.nx) return;
+    const int z = g.gz0 + k;
+    const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
+    const size_t o = (size_t)(k + 1) * ps + (size_t)y * rs + x;
+    const float *ex = a.e_n[0], *ey = a.e_n[1], *ez = a.e_n[2];
+    if (x >= 1 && x <= g.nx - 2 && y <= g.ny - 2 && z >= 0 && z <= g.gnz - 2)
+        a.h[0][o] = a.h[0][o] - g.kh_y * (ez[o + rs] - ez[o]) + g.kh_y * (ey[o + ps] - ey[o]);
+    if (x <= g.nx - 2 && y >= 1 && y <= g.ny - 2 && z >= 0 && z <= g.gnz - 2)
+        a.h[1][o] = a.h[1][o] - g.kh_z * (ex[o + ps] - ex[o]) + g.kh_x * (ez[o + 1] - ez[o]);
+    if (k >= 0 && x <= g.nx - 2 && y <= g.ny - 2 && z >= 1 && z <= g.gnz - 2)
+        a.h[2][o] = a.h[2][o] - g.kh_x * (ey[o + 1] - ey[o]) + g.kh_y * (ex[o + rs] - ex[o]);
+}
+
+// updateDField + updateSources + updateEField, fdtd_calculations.cu:80-213.
+__global__ __launch_bounds__(256) void fdtd3d_de(const Sweep3D a)
+{
+    const Grid3D &g = a.g;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int k = blockIdx.z;
+    if (x >= g.nx) return;
+    const int z = g.gz0 + k;
+    const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
+    const size_t o = (size_t)(k + 1) * ps + (size_t)y * rs + x;
+    const float *hx = a.h[0], *hy = a.h[1], *hz = a.h[2];
+
+    const bool x_lo = x >= 1, x_in = x <= g.nx - 2;
+    const bool y_lo = y >= 1, y_in = y <= g.ny - 2;
+    const bool z_lo = z >= 1, z_in = z <= g.gnz - 2;
+
+    float d0[3], d1[3], dn[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d0[c] = a.d_n[c][o];
+        d1[c] = a.d_w[c][o];
+        dn[c] = d1[c];
+    }
+    if (x_in && y_lo && y_in && z_lo && z_in) {
+        dn[0] = (d0[0] + g.cy * (hz[o] - hz[o - rs])) - g.cz * (hy[o] - hy[o - ps]);
+        a.d_w[0][o] = dn[0];
+    }
+    if (x_lo && x_in && y_in && z_lo && z_in) {
+        dn[1] = (d0[1] + g.cz * (hx[o] - hx[o - ps])) - g.cx * (hz[o] - hz[o - 1]);
+        a.d_w[1][o] = dn[1];
+    }
+    const bool src = is_source3d(a.src, x, y, z);
+    if ((x_lo && x_in && y_lo && y_in && z_in) || src) {
+        const float v = (d0[2] + g.cx * (hy[o] - hy[o - 1])) - g.cy * (hx[o] - hx[o - rs]);
+        dn[2] = src ? v - a.src.jz : v;
+        a.d_w[2][o] = dn[2];
+    }
+
+    const bool g_ex = x_in && y_lo && y_in && z_lo && z_in;
+    const bool g_eyz = x_lo && z_lo;
+    if (g_ex || g_eyz) {
+        const MatCoef m = a.table[a.code[o]];
+        if (g_ex) a.e_w[0][o] = e_update(m, a.e_n[0][o], a.e_w[0][o], dn[0], d0[0], d1[0]);
+        if (g_eyz) {
+            a.e_w[1][o] = e_update(m, a.e_n[1][o], a.e_w[1][o], dn[1], d0[1], d1[1]);
+            a.e_w[2][o] = e_update(m, a.e_n[2][o], a.e_w[2][o], dn[2], d0[2], d1[2]);
+        }
+    }
+}
+
+// updateMurBoundary, fdtd_calculations.cu:216-428: one thread per face cell,
+// the two components that face carries.
+__global__ __launch_bounds__(256) void fdtd3d_mur(const Mur3D a)
+{
+    const Grid3D &g = a.g;
+    const long nxf = 2L * g.ny * g.nzl, nyf = 2L * g.nx * g.nzl, nzf = 2L * g.nx * g.ny;
+    long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
+    float *ext = a.e_t[0], *eyt = a.e_t[1], *ezt = a.e_t[2];
+    const float *exs = a.e_s[0], *eys = a.e_s[1], *ezs = a.e_s[2];
+    const float dt = a.dt, mu0 = a.mu0, eps0 = a.eps0;
+
+    if (t < nxf) { // x faces: ey (:303-329) and ez (:369-395)
+        const int side = (int)(t / ((long)g.ny * g.nzl));
+        const long r = t % ((long)g.ny * g.nzl);
+        const int k = (int)(r / g.ny), y = (int)(r % g.ny);
+        const int z = g.gz0 + k;
+        const size_t base = (size_t)(k + 1) * ps + (size_t)y * rs;
+        const float *rp = side ? a.rp[FDTD_RP_XEND] : a.rp[FDTD_RP_X0];
+        const size_t ri = ((size_t)z * g.ny + y) * 2;
+        const float r_here = side ? rp[ri + 1] : rp[ri], r_in = side ? rp[ri] : rp[ri + 1];
+        const size_t f = base + (side ? g.nx - 1 : 0), in = base + (side ? g.nx - 2 : 1);
+        if (y <= g.ny - 2 && z >= 1 && z <= g.gnz - 2) {
+            // the high face takes eySource for both interior terms (:323, :325)
+            const float et_in = side ? eys[in] : eyt[in];
+            eyt[f] = mur_face(dt, a.dx, mu0, eps0, r_here, r_in, et_in, eys[in], eys[f]);
+        }
+        if (y >= 1 && y <= g.ny - 2 && z <= g.gnz - 2)
+            ezt[f] = mur_face(dt, a.dx, mu0, eps0, r_here, r_in, ezt[in], ezs[in], ezs[f]);
+        return;
+    }
+    t -= nxf;
+    if (t < nyf) { // y faces: ex (:237-263) and ez (:401-427)
+        const int side = (int)(t / ((long)g.nx * g.nzl));
+        const long r = t % ((long)g.nx * g.nzl);
+        const int k = (int)(r / g.nx), x = (int)(r % g.nx);
+        const int z = g.gz0 + k;
+        const size_t base = (size_t)(k + 1) * ps + x;
+        const float *rp = side ? a.rp[FDTD_RP_YEND] : a.rp[FDTD_RP_Y0];
+        const size_t ri = (size_t)z * 2 * g.nx + x;
+        const float r_here = side ? rp[ri + g.nx] : rp[ri], r_in = side ? rp[ri] : rp[ri + g.nx];
+        const size_t f = base + (side ? (size_t)(g.ny - 1) * rs : 0);
+        const size_t in = base + (side ? (size_t)(g.ny - 2) * rs : rs);
+        if (x <= g.nx - 2 && z >= 1 && z <= g.gnz - 2)
+            ext[f] = mur_face(dt, a.dy, mu0, eps0, r_here, r_in, ext[in], exs[in], exs[f]);
+        if (x >= 1 && x <= g.nx - 2 && z <= g.gnz - 2)
+            ezt[f] = mur_face(dt, a.dy, mu0, eps0, r_here, r_in, ezt[in], ezs[in], ezs[f]);
+        return;
+    }
+    t -= nyf;
+    if (t < nzf) { // z faces: ex (:269-295) and ey (:335-361); first and last slab only
+        const int side = (int)(t / ((long)g.nx * g.ny));
+        const long r = t % ((long)g.nx * g.ny);
+        const int y = (int)(r / g.nx), x = (int)(r % g.nx);
+        if (side == 0 ? g.gz0 != 0 : g.gz0 + g.nzl != g.gnz) return;
+        const int k = side ? g.nzl - 1 : 0, kin = side ? g.nzl - 2 : 1;
+        const float *rp = side ? a.rp[FDTD_RP_ZEND] : a.rp[FDTD_RP_Z0];
+        const size_t ri = (size_t)y * g.nx + x, rl = (size_t)g.ny * g.nx;
+        const float r_here = side ? rp[ri + rl] : rp[ri], r_in = side ? rp[ri] : rp[ri + rl];
+        const size_t f = (size_t)(k + 1) * ps + (size_t)y * rs + x;
+        const size_t in = (size_t)(kin + 1) * ps + (size_t)y * rs + x;
+        if (x <= g.nx - 2 && y >= 1 && y <= g.ny - 2)
+            ext[f] = mur_face(dt, a.dz, mu0, eps0, r_here, r_in, ext[in], exs[in], exs[f]);
+        if (x >= 1 && x <= g.nx - 2 && y <= g.ny - 2)
+            eyt[f] = mur_face(dt, a.dz, mu0, eps0, r_here, r_in, eyt[in], eys[in], eys[f]);
+    }
+}
+
+// ------------------------------------------------------------------ probes
+
+__global__ void fdtd2d_probe(const Probe2D a)
+{
+    const int i = threadIdx.x;
+    if (i >= a.p.count) return;
+    const int j = a.p.y[i] - a.g.gy0;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (j >= 0 && j < a.g.nyl && a.p.x[i] >= 0 && a.p.x[i] < a.g.nx) {
+        const size_t o = (size_t)(j + 1) * a.g.pitch + a.p.x[i];
+        v[0] = a.hx[o];
+        v[1] = a.hy[o];
+        v[2] = a.dz[o];
+        v[3] = a.ez[o];
+    }
+    float *dst = a.ring + ((size_t)a.slot * FDTD_MAX_PROBES + i) * 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = v[c];
+}
+
+__global__ void fdtd3d_probe(const Probe3D a)
+{
+    const int i = threadIdx.x;
+    if (i >= a.p.count) return;
+    const int k = a.p.z[i] - a.g.gz0;
+    float *dst = a.ring + ((size_t)a.slot * FDTD_MAX_PROBES + i) * 9;
+    const bool in = k >= 0 && k < a.g.nzl && a.p.x[i] >= 0 && a.p.x[i] < a.g.nx && a.p.y[i] >= 0 &&
+                    a.p.y[i] < a.g.ny;
+    const size_t o = in ? ((size_t)(k + 1) * a.g.ny + a.p.y[i]) * a.g.pitch + a.p.x[i] : 0;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) dst[c] = in ? a.f[c][o] : 0.f;
+}
+
+__global__ void fill_u8_kernel(uint8_t *p, size_t n, uint8_t v)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ launchers
+// Every launcher checks on the host that the grid it builds matches what the
+// kernel indexes; the callers guarantee the array extents (context.hip).
+
+static inline hipStream_t S(void *s) { return (hipStream_t)s; }
+
+void launch_h2d(const Sweep2D &a, void *stream)
+{
+    dim3 grid((a.g.nx + 255) / 256, a.g.nyl + a.g.has_lower, 1);
+    hipLaunchKernelGGL(fdtd2d_h, grid, dim3(256), 0, S(stream), a);
+}
+
+void launch_de2d(const Sweep2D &a, void *stream)
+{
+    dim3 grid((a.g.nx + 255) / 256, a.g.nyl, 1);
+    hipLaunchKernelGGL(fdtd2d_de, grid, dim3(256), 0, S(stream), a);
+}
+
+void launch_sweep2d(const Sweep2D &a, void *stream)
+{
+    const int chunks = (a.g.nyl + a.chunk_rows - 1) / a.chunk_rows;
+    dim3 grid((a.g.nx + 1023) / 1024, chunks, 1);
+    hipLaunchKernelGGL(fdtd2d_sweep, grid, dim3(256), 0, S(stream), a);
+}
+
+void launch_mur2d(const Mur2D &a, void *stream)
+{
+    const long total = 2L * a.g.nyl + 2L * a.g.nx;
+    hipLaunchKernelGGL(fdtd2d_mur, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), a);
+}
+
+void launch_h3d(const Sweep3D &a, void *stream)
+{
+    dim3 grid((a.g.nx + 255) / 256, a.g.ny, a.g.nzl + a.g.has_lower);
+    hipLaunchKernelGGL(fdtd3d_h, grid, dim3(256), 0, S(stream), a);
+}
+
+void launch_de3d(const Sweep3D &a, void *stream)
+{
+    dim3 grid((a.g.nx + 255) / 256, a.g.ny, a.g.nzl);
+    hipLaunchKernelGGL(fdtd3d_de, grid, dim3(256), 0, S(stream), a);
+}
+
+void launch_mur3d(const Mur3D &a, void *stream)
+{
+    const long total = 2L * a.g.ny * a.g.nzl + 2L * a.g.nx * a.g.nzl + 2L * a.g.nx * a.g.ny;
+    hipLaunchKernelGGL(fdtd3d_mur, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), a);
+}
+
+void launch_probe2d(const Probe2D &a, void *stream)
+{
+    hipLaunchKernelGGL(fdtd2d_probe, dim3(1), dim3(64), 0, S(stream), a);
+}
+
+void launch_probe3d(const Probe3D &a, void *stream)
+{
+    hipLaunchKernelGGL(fdtd3d_probe, dim3(1), dim3(64), 0, S(stream), a);
+}
+
+void launch_fill_u8(uint8_t *p, size_t n, uint8_t v, void *stream)
+{
+    hipLaunchKernelGGL(fill_u8_kernel, dim3(2048), dim3(256), 0, S(stream), p, n, v);
+}
+
+const char *sweep2d_kernel_name() { return "fdtd2d_sweep"; }
+const char *de2d_kernel_name() { return "fdtd2d_de"; }
+const char *de3d_kernel_name() { return "fdtd3d_de"; }
+
+} // namespace fdtd

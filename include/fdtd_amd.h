@@ -1,0 +1,206 @@
+/*
+ * fdtd_amd.h -- C ABI of the MI355X (gfx950) FDTD field-update library.
+ *
+ * The reference (UnalignedByte/fdtd) has no plugin or FFI layer: its update
+ * path sits behind `main` (fdtd.cu:46-544) and six symbols in
+ * fdtd_calculations.h:18-42.  Each entry point below names the reference code
+ * it replaces.  Conventions: plain pointers and sizes only; `int` return,
+ * 0 = success, < 0 = error with the message available from fdtd_last_error();
+ * the library never calls exit(); the caller owns host buffers, the library
+ * owns every device buffer; one context must not be used from two threads at
+ * once.  All field data is fp32, cell (x, y, z) of a full field lives at
+ * z*ny*nx + y*nx + x (utils.h:15).
+ */
+#ifndef FDTD_AMD_H
+#define FDTD_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDTD_MAX_SOURCES 16 /* fdtd_calculations.h:7 */
+#define FDTD_MAX_JZ 512     /* fdtd_calculations.h:8 */
+#define FDTD_MAX_CODES 256  /* material codes; the reference table (fdtd.cu:878) has 94 and overflows */
+#define FDTD_MAX_PROBES 16
+
+/* Mirror of FdtdParams (fdtd.h:7-34) with fixed-size members.  jz holds the
+ * FDTD_MAX_JZ samples that reach the kernels (fdtd_calculations.cu:27-28);
+ * the sample index of step n is n - n % 3 (fdtd.cu:172,310,448) and samples
+ * past the table are 0. */
+typedef struct fdtd_params {
+    int32_t nx, ny, nz;
+    int32_t iterations;                 /* rounded up to a multiple of 3, fdtd.cu:563 */
+    char input_path[1024];              /* env_set_dir: directory of the v1_%05d.pgm slices */
+    char output_path[1024];             /* output_dir */
+    int32_t elements_per_wave;
+    float wave_frequency;
+    float pulse_width;
+    float pulse_modulation_frequency;
+    int32_t sources_count;
+    int32_t sources[FDTD_MAX_SOURCES * 3]; /* 0-based x, y, z (fdtd.cu:607-609) */
+    float default_sigma, default_eps_s, default_eps_i, default_tau_d;
+    int32_t jz_count;
+    float jz[FDTD_MAX_JZ];
+    float pi, c, timeskip, lambda, dt, dx, dy, dz, mu0, eps0;
+} fdtd_params;
+
+enum { FDTD_MODE_AUTO = 0, FDTD_MODE_3D = 1, FDTD_MODE_2D_TMZ = 2 };
+/* d = 2b - sigma*dt^2 as written in fdtd_calculations.cu:144 (fields grow ~2x
+ * per step in vacuum), or d = a + b - sigma*dt^2 (bounded). */
+enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
+/* SPLIT: an H kernel and a fused D+source+E kernel (H updated in place).
+ * FUSED: one sweep per step (2-D only; H double-buffered). */
+enum { FDTD_KERNEL_AUTO = 0, FDTD_KERNEL_SPLIT = 1, FDTD_KERNEL_FUSED = 2 };
+
+typedef struct fdtd_options {
+    int32_t mode;        /* FDTD_MODE_*; AUTO = 2-D TMz when nz == 1 */
+    int32_t ecoef;       /* FDTD_ECOEF_* */
+    int32_t device;      /* HIP device ordinal */
+    int32_t kernel;      /* FDTD_KERNEL_* */
+    int32_t slab_begin;  /* first global row of the slab axis held here (y in 2-D, z in 3-D) */
+    int32_t slab_count;  /* rows held; 0 = the whole grid */
+    int32_t chunk_rows;  /* rows marched by one workgroup of the fused sweep; 0 = default */
+    int32_t reserved[9];
+} fdtd_options;
+
+/* Field ids (read/write/snapshot/probe). */
+enum {
+    FDTD_HX = 0, FDTD_HY, FDTD_HZ,
+    FDTD_DX, FDTD_DY, FDTD_DZ,
+    FDTD_EX, FDTD_EY, FDTD_EZ,
+    FDTD_NFIELDS
+};
+/* Mur coefficient planes (fdtd.h:52-53). */
+enum { FDTD_RP_X0 = 0, FDTD_RP_Y0, FDTD_RP_Z0, FDTD_RP_XEND, FDTD_RP_YEND, FDTD_RP_ZEND };
+
+typedef struct fdtd_ctx fdtd_ctx;
+
+const char *fdtd_last_error(void);
+void fdtd_options_default(fdtd_options *opt);
+
+/* ---- input surface ---------------------------------------------------- */
+
+/* initParamsWithPath (fdtd.cu:547-637) followed by setupSources
+ * (fdtd.cu:1027-1082): positional parse of a data/input_params file, derived
+ * constants, jz table. */
+int fdtd_params_load(const char *path, fdtd_params *out);
+/* fdtd.cu:625-634 on a struct filled in by the caller. */
+int fdtd_params_derive(fdtd_params *p);
+/* setupSources (fdtd.cu:1027-1082) on a struct whose constants are derived. */
+int fdtd_setup_sources(fdtd_params *p);
+
+/* Host-only pieces of the input surface, usable without a GPU. */
+
+/* First half of loadMaterials (fdtd.cu:878-904): parse a mat_specs file into
+ * table4[code*4 + {0,1,2,3}] = sigma, eps_s, eps_inf, tau_d (256 rows) and
+ * present[code] = 1 for the codes the file defines. */
+int fdtd_read_material_specs(const char *path, float *table4, uint8_t *present);
+/* Second half of loadMaterials (fdtd.cu:909-936) for one slice file: the codes
+ * of rows [y0, y0 + rows) of an nx x ny grid, x fastest, into dst. */
+int fdtd_read_pgm_codes(const char *path, int nx, int ny, int upsample, int y0, int rows, uint8_t *dst);
+/* The E-update coefficients of one material (fdtd_calculations.cu:141-156):
+ * acd[3] = a, c, d (fp32) and k[3] = 2(dt+tau), 2dt+4tau, 2tau (fp64). */
+int fdtd_material_coefficients(const fdtd_params *p, int ecoef, float sigma, float eps_s, float eps_inf,
+                               float tau_d, float acd[3], double k[3]);
+/* One value of an rp plane (fdtd.cu:959-963 for the x faces, :983-987 for the
+ * y and z faces) for a material. */
+float fdtd_rp_value(const fdtd_params *p, int x_face, float sigma, float eps_s, float eps_inf, float tau_d);
+
+/* ---- context ---------------------------------------------------------- */
+
+/* initDeviceFieldWithParams + copyDataToDevice + setupMurBoundary +
+ * copySymbolsToDevice (fdtd.cu:764-822, 1085-1133, 942-1024;
+ * fdtd_calculations.cu:7-29): allocates the padded SoA fields on the device,
+ * zeroes them, fills every cell with the default material and derives the rp
+ * planes from the defaults (the reference runs setupMurBoundary before
+ * loadMaterials, fdtd.cu:59 vs :65). */
+int fdtd_create(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx **out);
+void fdtd_destroy(fdtd_ctx *ctx);
+
+/* loadMaterials (fdtd.cu:875-939): mat_specs file + one P2 PGM per z slice,
+ * `<pgm_dir>/v1_%05d.pgm`, nx*ny tokens read in sequence.  first_slice is the
+ * 1-based index of the slice for z = 0 (the reference always uses 1);
+ * upsample >= 1 repeats each PGM pixel upsample x upsample times in x and y
+ * (nearest neighbour; 1 = the reference behaviour). */
+int fdtd_load_materials(fdtd_ctx *ctx, const char *specs_path, const char *pgm_dir,
+                        int first_slice, int upsample);
+/* The two halves of loadMaterials on caller data: one table row per material
+ * code (sigma, eps_s, eps_inf, tau_d; fdtd.cu:897-900) and the per-cell code
+ * map (fdtd.cu:922-931; `count` = cells of the slab held, x fastest). */
+int fdtd_set_material(fdtd_ctx *ctx, int code, float sigma, float eps_s, float eps_inf, float tau_d);
+int fdtd_set_codes(fdtd_ctx *ctx, const uint8_t *codes, size_t count);
+/* Replace one rp plane (layouts of fdtd.cu:952-1001, global extents). */
+int fdtd_set_rp(fdtd_ctx *ctx, int face, const float *data, size_t count);
+int fdtd_get_rp(fdtd_ctx *ctx, int face, float *data, size_t count);
+/* setupMurBoundary (fdtd.cu:942-1024) evaluated on the materials now loaded
+ * (opt-in: the reference only ever evaluates it on the defaults). */
+int fdtd_setup_mur_from_materials(fdtd_ctx *ctx);
+
+/* ---- time stepping ---------------------------------------------------- */
+
+/* The hot loop (fdtd.cu:115-530): nsteps x { updateHField, updateDField,
+ * updateSources, updateEField, updateMurBoundary } (fdtd_calculations.cu:32-428).
+ * Asynchronous: returns once the work is queued on the context's stream. */
+int fdtd_step(fdtd_ctx *ctx, int nsteps);
+int fdtd_sync(fdtd_ctx *ctx);
+int64_t fdtd_steps_done(const fdtd_ctx *ctx);
+
+/* Per-step device timing of the field sweep with HIP events on the stream the
+ * kernels run on.  After fdtd_profile_begin(ctx, capacity) each step records
+ * an event pair around its main sweep; fdtd_profile_read() synchronises and
+ * returns the milliseconds of up to `capacity` steps. */
+int fdtd_profile_begin(fdtd_ctx *ctx, int capacity);
+int fdtd_profile_read(fdtd_ctx *ctx, float *sweep_ms, int capacity, int *count);
+/* Name of the kernel that does the main sweep (as a profiler reports it). */
+const char *fdtd_sweep_kernel_name(const fdtd_ctx *ctx);
+
+/* ---- results ---------------------------------------------------------- */
+
+/* Synchronous copy of one field of the slab held (newest time level) to or
+ * from host memory, unpadded, `count` = nx * rows * (ny or 1) floats.  This is
+ * what the cudaMemcpyAsync + copy threads of fdtd.cu:134-136,176-178,221-223
+ * deliver.  level 0 = newest, 1 = previous time level (E and D only). */
+int fdtd_read_field(fdtd_ctx *ctx, int field, int level, float *dst, size_t count);
+int fdtd_write_field(fdtd_ctx *ctx, int field, int level, const float *src, size_t count);
+
+/* Snapshot of one field on a side stream: a device-to-device copy ordered
+ * after the steps queued so far, then an async D2H into pinned staging; the
+ * steps queued afterwards do not wait for the D2H.  fdtd_snapshot_wait()
+ * blocks until the data is in dst. */
+int fdtd_snapshot_async(fdtd_ctx *ctx, int field, float *dst, size_t count);
+int fdtd_snapshot_wait(fdtd_ctx *ctx);
+
+/* Probe time series: up to FDTD_MAX_PROBES cells (global 0-based x, y, z);
+ * after every step the values of hx, hy, dz, ez (2-D) or all nine fields (3-D)
+ * at the probes held by this slab are appended to a device ring of `capacity`
+ * steps.  fdtd_read_probes() copies rows [first_step, first_step + nsteps) as
+ * [step][probe][field] floats; probes outside the slab read as 0. */
+int fdtd_set_probes(fdtd_ctx *ctx, int count, const int32_t *xyz, int capacity);
+int fdtd_probe_fields(const fdtd_ctx *ctx);
+int fdtd_read_probes(fdtd_ctx *ctx, int64_t first_step, int nsteps, float *dst, size_t count);
+
+/* ---- slabs across GPUs ------------------------------------------------ */
+
+/* Halo rows of the slab axis.  side 0 = towards lower indices, 1 = towards
+ * higher.  fdtd_halo_get() copies the rows a neighbour needs (the first or
+ * last owned rows of the newest E level) to the host; fdtd_halo_put() stores
+ * rows received from that neighbour into the halo.  `count` must equal
+ * fdtd_halo_count().  These are the host-staged form of the exchange. */
+size_t fdtd_halo_count(const fdtd_ctx *ctx);
+int fdtd_halo_get(fdtd_ctx *ctx, int side, float *dst, size_t count);
+int fdtd_halo_put(fdtd_ctx *ctx, int side, const float *src, size_t count);
+
+/* RCCL form of the exchange: rank 0 creates an id (128 bytes), every rank
+ * passes it to fdtd_comm_init(); afterwards fdtd_step() exchanges halos with
+ * ranks rank-1 and rank+1 after every step (ncclSend/ncclRecv in one group)
+ * on the context's stream.  The slab of rank r must be the r-th slab. */
+int fdtd_comm_unique_id(char id[128]);
+int fdtd_comm_init(fdtd_ctx *ctx, const char id[128], int rank, int world);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

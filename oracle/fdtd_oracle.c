@@ -516,6 +516,26 @@ static inline ecoefs e_coefs(const orc_state *s, size_t i)
     return k;
 }
 
+void orc_cell_coefs(const orc_state *s, size_t cell, float abcd[4])
+{
+    ecoefs k = e_coefs(s, cell);
+    abcd[0] = k.a;
+    abcd[1] = k.b;
+    abcd[2] = k.c;
+    abcd[3] = k.d;
+}
+
+float *orc_material(orc_state *s, int which)
+{
+    switch (which) {
+    case 0: return s->sigma;
+    case 1: return s->eps_s;
+    case 2: return s->eps_i;
+    case 3: return s->tau_d;
+    default: return NULL;
+    }
+}
+
 /* fdtd_calculations.cu:150-156 */
 static inline float e_update(const orc_state *s, size_t i, ecoefs k, float e0, float e1, float d0,
                              float d1, float d2)

@@ -109,6 +109,12 @@ float *orc_field(orc_state *s, int field_id);
 float *orc_field_level(orc_state *s, int field_id, int level);
 size_t orc_field_count(const orc_state *s);
 
+/* Per-cell material arrays in storage order: 0 sigma, 1 eps_s, 2 eps_i, 3 tau_d. */
+float *orc_material(orc_state *s, int which);
+/* The E-update coefficients a, b, c, d of one storage cell
+ * (fdtd_calculations.cu:141-144). */
+void orc_cell_coefs(const orc_state *s, size_t cell, float abcd[4]);
+
 /* Timed run for the CPU baseline: returns seconds for nsteps steps. */
 double orc_time_steps(orc_state *s, int nsteps, int threads);
 

@@ -90,6 +90,10 @@ def lib():
         L.orc_field_level.restype = C.POINTER(C.c_float)
         L.orc_field_count.argtypes = [vp]
         L.orc_field_count.restype = C.c_size_t
+        L.orc_material.argtypes = [vp, ci]
+        L.orc_material.restype = C.POINTER(C.c_float)
+        L.orc_cell_coefs.argtypes = [vp, C.c_size_t, C.c_void_p]
+        L.orc_cell_coefs.restype = None
         L.orc_time_steps.argtypes = [vp, ci, ci]
         L.orc_time_steps.restype = C.c_double
         _lib = L
@@ -196,6 +200,16 @@ class Oracle:
         rc = lib().orc_set_materials(self._s, full.ctypes.data, table.ctypes.data, table.shape[0])
         if rc != 0:
             raise RuntimeError(f"orc_set_materials = {rc}")
+
+    def material(self, which):
+        """Per-cell sigma (0), eps_s (1), eps_i (2) or tau_d (3), halo rows dropped."""
+        a = self._view(lib().orc_material(self._s, which))
+        return a[:, 1:-1, :] if self.mode == MODE_2D_TMZ else a
+
+    def cell_coefs(self, cell):
+        out = np.zeros(4, dtype=np.float32)
+        lib().orc_cell_coefs(self._s, cell, out.ctypes.data)
+        return out
 
     def setup_mur(self):
         lib().orc_setup_mur(self._s)

@@ -1,0 +1,275 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on
+the same inputs.  Contract per field: max|hip - oracle| <= 1e-5 * running peak
+of the oracle field (tests/util.py); both sides evaluate the same IEEE
+operations in the same order, so the tests also require bit-identity."""
+import os
+
+import numpy as np
+import pytest
+
+import fdtd_amd
+from fdtd_amd import binding as B
+from conftest import DATA
+import util
+
+pytestmark = pytest.mark.gpu
+
+REF, CON = B.ECOEF_REFERENCE, B.ECOEF_CONSISTENT
+
+
+# ------------------------------------------------------------------ 3-D
+
+def test_3d_shipped_case_against_recorded_probe_series(golden):
+    """data/input_params (100^3 vacuum, REFERENCE coefficients): dz, ez, hy at the
+    source after steps 1..110 against the recorded reference outputs."""
+    p = fdtd_amd.params_load(os.path.join(DATA, "input_params"))
+    s = fdtd_amd.Solver(p, ecoef=REF)
+    s.set_probes([[49, 49, 49], [50, 49, 49]], capacity=128)
+    s.step(111)
+    pr = s.read_probes(0, 111)          # [step][probe][hx hy hz dx dy dz ex ey ez]
+    for step, dz, ez, ezx, hy in golden["probe_series_100cube_vacuum_reference"]["rows"]:
+        got = (pr[step - 1, 0, B.DZ], pr[step - 1, 0, B.EZ], pr[step - 1, 1, B.EZ], pr[step - 1, 0, B.HY])
+        for g, w in zip(got, (dz, ez, ezx, hy)):
+            w = float(w)
+            if np.isinf(w):
+                assert g == w
+            else:
+                assert f"{float(g):.8e}" == f"{w:.8e}", (step, got)
+
+
+def test_3d_vacuum_fields_match_oracle(oracle):
+    s, o = util.pair(oracle, (100, 100, 100), [(49, 49, 49)], REF)
+    assert util.run_and_compare(s, o, 90, 30, "100^3 vacuum") == 0
+
+
+@pytest.mark.parametrize("dims,ecoef", [((23, 19, 17), REF), ((23, 19, 17), CON), ((64, 5, 9), CON),
+                                         ((3, 3, 3), REF), ((130, 7, 4), REF)])
+def test_3d_random_state_debye_and_mur(oracle, dims, ecoef):
+    """Random fields, random tissue map, non-uniform rp planes, two sources: every
+    term of every kernel (all 12 Mur cases, the ey high-x quirk) is exercised."""
+    nx, ny, nz = dims
+    rng = np.random.default_rng(1234 + nx)
+    srcs = [(nx // 2, ny // 2, nz // 2), (nx - 1, ny - 1, nz - 1)]
+    s, o = util.pair(oracle, dims, srcs, ecoef, sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=(nz, ny, nx), dtype=np.uint8)
+    util.set_materials(s, o, codes)
+    for face in range(6):
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    util.randomize(s, o, rng)
+    assert util.run_and_compare(s, o, 12, 3, f"{dims}") == 0
+
+
+def test_3d_mur_from_loaded_materials(oracle):
+    dims = (12, 11, 10)
+    rng = np.random.default_rng(5)
+    s, o = util.pair(oracle, dims, [(6, 5, 5)], CON)
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=dims[::-1], dtype=np.uint8)
+    util.set_materials(s, o, codes)
+    s.setup_mur_from_materials()
+    o.setup_mur()
+    for face in range(6):
+        assert np.array_equal(s.rp(face), o.rp(face)), face
+    assert util.run_and_compare(s, o, 30, 10, "rp from materials") == 0
+
+
+# ------------------------------------------------------------------ 2-D TMz
+
+KERNELS = [B.KERNEL_FUSED, B.KERNEL_SPLIT]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dims,src,chunk", [
+    ((265, 490), [(130, 245)], 0),
+    ((1030, 37), [(255, 5), (256, 6), (257, 7), (1023, 8), (1024, 9), (1029, 36)], 5),
+    ((300, 70), [(1, 1), (299, 69), (150, 63), (150, 64)], 64),
+    ((3, 3), [(1, 1)], 1),
+    ((7, 5), [(3, 2)], 2),
+    ((2049, 11), [(2047, 5), (2048, 6)], 3),
+])
+def test_2d_vacuum_point_sources(oracle, kernel, dims, src, chunk):
+    """Sources on strip edges (x = 255/256, 1023/1024), chunk edges and grid edges."""
+    nx, ny = dims
+    s, o = util.pair(oracle, (nx, ny, 1), [(x, y, 0) for x, y in src], CON, kernel=kernel, chunk_rows=chunk)
+    assert util.run_and_compare(s, o, 120, 40, f"2-D {dims}") == 0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_2d_reference_coefficients_until_overflow_window(oracle, kernel):
+    s, o = util.pair(oracle, (200, 180, 1), [(100, 90, 0)], REF, kernel=kernel)
+    assert util.run_and_compare(s, o, 90, 30, "2-D REFERENCE") == 0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("dims,chunk", [((265, 49), 7), ((1100, 21), 4), ((70, 130), 64)])
+def test_2d_random_state_debye_and_mur(oracle, kernel, dims, chunk):
+    nx, ny = dims
+    rng = np.random.default_rng(99 + nx)
+    s, o = util.pair(oracle, (nx, ny, 1), [(nx // 2, ny // 2, 0), (nx - 1, ny - 1, 0)], CON, kernel=kernel,
+                     chunk_rows=chunk, sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=(1, ny, nx), dtype=np.uint8)
+    util.set_materials(s, o, codes)
+    for face in (0, 1, 3, 4):
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    util.randomize(s, o, rng)
+    assert util.run_and_compare(s, o, 15, 5, f"2-D random {dims}") == 0
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_2d_pgm_tissue_slice_1000_steps(oracle, kernel):
+    """Config 1b: data/input_params physics on the 265x490 body slice v1_00800,
+    mat_specs_riken tissues, source in air next to the body, 1000 steps."""
+    nx, ny = 265, 490
+    pa = fdtd_amd.make_params(nx, ny, 1, [(40, 245, 0)])
+    po = oracle.make_params(nx, ny, 1, [(40, 245, 0)])
+    s = fdtd_amd.Solver(pa, ecoef=CON, kernel=kernel)
+    o = oracle.Oracle(po, ecoef=CON)
+    specs, pgm = os.path.join(DATA, "mat_specs_riken"), os.path.join(DATA, "pgmdata")
+    s.load_materials(specs, pgm, first_slice=800)
+    o.load_materials(specs, pgm, first_slice=800)
+    assert util.run_and_compare(s, o, 1000, 250, "PGM slice") == 0
+    ez = s.field(B.EZ)
+    assert np.isfinite(ez).all() and np.abs(ez).max() > 0
+
+
+def test_2d_upsampled_pgm_matches_oracle_on_repeated_codes(oracle):
+    nx, ny, u = 265 * 2, 490 * 2, 2
+    pa = fdtd_amd.make_params(nx, ny, 1, [(60, 490, 0)])
+    po = oracle.make_params(nx, ny, 1, [(60, 490, 0)])
+    s = fdtd_amd.Solver(pa, ecoef=CON)
+    o = oracle.Oracle(po, ecoef=CON)
+    specs, pgm = os.path.join(DATA, "mat_specs_riken"), os.path.join(DATA, "pgmdata")
+    s.load_materials(specs, pgm, first_slice=800, upsample=u)
+    table, _ = B.read_material_specs(specs)
+    codes = B.read_pgm_codes(os.path.join(pgm, "v1_00800.pgm"), 265, 490)
+    o.set_materials(np.repeat(np.repeat(codes, u, axis=0), u, axis=1)[None], table)
+    assert util.run_and_compare(s, o, 300, 100, "upsampled PGM") == 0
+
+
+# ------------------------------------------------------------------ slabs
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("world", [2, 3])
+def test_2d_slabs_equal_whole_grid(oracle, kernel, world):
+    """world slabs on one GPU, halos staged through the host after every step:
+    bit-identical to the single-slab run (and so to the oracle)."""
+    nx, ny = 300, 101
+    rng = np.random.default_rng(7)
+    srcs = [(150, 50, 0), (20, 33, 0), (280, 34, 0)]
+    pa = fdtd_amd.make_params(nx, ny, 1, srcs, sigma=0.1, eps_s=5.0, eps_i=2.0, tau_d=1e-11)
+    whole = fdtd_amd.Solver(pa, ecoef=CON, kernel=kernel, chunk_rows=16)
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=(ny, nx), dtype=np.uint8)
+    parts = fdtd_amd.partition_rows(ny, world)
+    slabs = [fdtd_amd.Solver(pa, ecoef=CON, kernel=kernel, chunk_rows=16, slab=part) for part in parts]
+    for sv, (b, n) in zip([whole] + slabs, [(0, ny)] + parts):
+        for code, row in enumerate(util.RIKEN_LIKE):
+            sv.set_material(code, *[float(v) for v in row])
+        sv.set_codes(codes[b:b + n])
+    for _ in range(150):
+        whole.step(1)
+        for sv in slabs:
+            sv.step(1)
+        for r in range(world - 1):          # neighbours r and r + 1
+            up, down = slabs[r].halo_get(1), slabs[r + 1].halo_get(0)
+            slabs[r + 1].halo_put(0, up)
+            slabs[r].halo_put(1, down)
+    for fid in (B.HX, B.HY, B.DZ, B.EZ):
+        full = whole.field(fid)
+        got = np.concatenate([sv.field(fid) for sv in slabs], axis=1)
+        assert np.array_equal(full.view(np.uint32), got.view(np.uint32)), B.FIELD_NAMES[fid]
+    assert np.abs(whole.field(B.EZ)).max() > 0
+
+
+def test_3d_slabs_equal_whole_grid(oracle):
+    nx, ny, nz = 40, 21, 30
+    rng = np.random.default_rng(8)
+    srcs = [(20, 10, 15), (5, 5, 9), (5, 5, 10)]
+    pa = fdtd_amd.make_params(nx, ny, nz, srcs, sigma=0.1, eps_s=5.0, eps_i=2.0, tau_d=1e-11)
+    whole = fdtd_amd.Solver(pa, ecoef=CON)
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=(nz, ny, nx), dtype=np.uint8)
+    parts = fdtd_amd.partition_rows(nz, 3)
+    slabs = [fdtd_amd.Solver(pa, ecoef=CON, slab=part) for part in parts]
+    for sv, (b, n) in zip([whole] + slabs, [(0, nz)] + parts):
+        for code, row in enumerate(util.RIKEN_LIKE):
+            sv.set_material(code, *[float(v) for v in row])
+        sv.set_codes(codes[b:b + n])
+    for _ in range(60):
+        whole.step(1)
+        for sv in slabs:
+            sv.step(1)
+        for r in range(2):
+            up, down = slabs[r].halo_get(1), slabs[r + 1].halo_get(0)
+            slabs[r + 1].halo_put(0, up)
+            slabs[r].halo_put(1, down)
+    for fid in range(9):
+        full = whole.field(fid)
+        got = np.concatenate([sv.field(fid) for sv in slabs], axis=0)
+        assert np.array_equal(full.view(np.uint32), got.view(np.uint32)), B.FIELD_NAMES[fid]
+    assert np.abs(whole.field(B.EX)).max() > 0
+
+
+# ------------------------------------------------------------------ results path
+
+def test_probes_and_snapshot_agree_with_read_field(oracle):
+    s, o = util.pair(oracle, (400, 300, 1), [(200, 150, 0)], CON)
+    probes = [[200, 150, 0], [210, 150, 0], [200, 170, 0], [399, 299, 0]]
+    s.set_probes(probes, capacity=64)
+    snap = np.empty(s.shape, dtype=np.float32)
+    series = []
+    for step in range(50):
+        s.step(1)
+        o.step(1)
+        if step == 30:
+            s.snapshot_async(B.EZ, snap)        # the next steps overwrite this level
+            want_snap = np.array(o.field(B.EZ))
+        series.append([[o.field(f)[0, y, x] for f in (B.HX, B.HY, B.DZ, B.EZ)] for x, y, _ in probes])
+    s.snapshot_wait()
+    assert np.array_equal(snap.view(np.uint32), want_snap.view(np.uint32))
+    got = s.read_probes(0, 50)
+    assert np.array_equal(got.view(np.uint32), np.array(series, dtype=np.float32).view(np.uint32))
+    with pytest.raises(fdtd_amd.FdtdError):
+        s.read_probes(0, 51)
+
+
+def test_create_rejects_bad_inputs():
+    with pytest.raises(fdtd_amd.FdtdError, match="at least 3"):
+        fdtd_amd.Solver(fdtd_amd.make_params(2, 10, 1, [(1, 1, 0)]))
+    with pytest.raises(fdtd_amd.FdtdError, match="source_location"):
+        fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 1, [(0, 5, 0)]))
+    with pytest.raises(fdtd_amd.FdtdError, match="fused"):
+        fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 10, [(5, 5, 5)]), kernel=B.KERNEL_FUSED)
+    with pytest.raises(fdtd_amd.FdtdError, match="slab"):
+        fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 1, [(5, 5, 0)]), slab=(8, 5))
+    s = fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 1, [(5, 5, 0)]))
+    with pytest.raises(fdtd_amd.FdtdError, match="count"):
+        s.set_codes(np.zeros(7, dtype=np.uint8))
+    with pytest.raises(fdtd_amd.FdtdError, match="2-D"):
+        s.field(B.EX)
+
+
+# ------------------------------------------------------------------ full size
+
+def test_2d_full_size_16384_window_and_causality(oracle):
+    """16384 x 16384 vacuum + centre source (the benchmark workload), 200 steps.
+    Translation invariance: until the wave meets a boundary the solution only
+    depends on the distance to the source, so the 512 x 512 window around the
+    source must equal, bit for bit, an oracle run on a 512 x 512 grid.  Causality:
+    one step moves the field one cell in the 1-norm, so ez is exactly zero at
+    |x - sx| + |y - sy| > steps."""
+    n, steps, w = 16384, 200, 512
+    sx = sy = n // 2
+    s = fdtd_amd.Solver(fdtd_amd.make_params(n, n, 1, [(sx, sy, 0)]), ecoef=CON)
+    o = oracle.Oracle(oracle.make_params(w, w, 1, [(w // 2, w // 2, 0)]), ecoef=CON)
+    s.step(steps)
+    o.step(steps, threads=8)
+    for fid in (B.HX, B.HY, B.DZ, B.EZ):
+        full = s.field(fid)[0]
+        win = full[sy - w // 2: sy + w // 2, sx - w // 2: sx + w // 2]
+        assert np.array_equal(win.view(np.uint32), np.asarray(o.field(fid)[0]).view(np.uint32)), B.FIELD_NAMES[fid]
+        ys, xs = np.nonzero(full)
+        assert ys.size > 0
+        assert int(np.max(np.abs(ys - sy) + np.abs(xs - sx))) <= steps + 1
+        del full

@@ -1,0 +1,94 @@
+"""Helpers shared by the GPU parity tests: build the HIP solver and the oracle
+from the same inputs and compare their fields."""
+import numpy as np
+
+import fdtd_amd
+from fdtd_amd import binding as B
+
+# max |hip - oracle| <= TOL * (largest |oracle| value the field reached), per field
+TOL = 1e-5
+
+RIKEN_LIKE = np.array([
+    # sigma, eps_s, eps_inf, tau_d
+    [0.0, 1.0, 1.0, 0.0],
+    [0.59515458, 56.44398499, 33.05709076, 3.51972652e-11],
+    [0.10401546, 14.16905880, 7.36329556, 3.41064989e-11],
+    [0.03710634, 5.53071189, 3.99812841, 2.36329289e-11],
+    [0.74710494, 56.93144607, 28.00134277, 1.86721420e-11],
+    [2.14390564, 70.39963913, 33.14797211, 1.81622616e-11],
+    [0.5, 4.0, 4.0, 0.0],
+], dtype=np.float32)
+
+
+def pair(oracle, dims, sources, ecoef, kernel=B.KERNEL_AUTO, chunk_rows=0, **kw):
+    """(Solver, Oracle) on identical parameters."""
+    nx, ny, nz = dims
+    pa = fdtd_amd.make_params(nx, ny, nz, sources, **kw)
+    po = oracle.make_params(nx, ny, nz, sources, **kw)
+    s = fdtd_amd.Solver(pa, ecoef=ecoef, kernel=kernel, chunk_rows=chunk_rows)
+    o = oracle.Oracle(po, ecoef=ecoef)
+    return s, o
+
+
+def fields_of(s):
+    return [B.HX, B.HY, B.DZ, B.EZ] if s.is2d else list(range(9))
+
+
+def set_materials(s, o, codes, table=RIKEN_LIKE):
+    for code, row in enumerate(table):
+        s.set_material(code, *[float(v) for v in row])
+    s.set_codes(codes)
+    o.set_materials(codes, table)
+
+
+def randomize(s, o, rng, scale=1.0):
+    """Same random state in both: H, and both time levels of D and E."""
+    for fid in fields_of(s):
+        levels = (0,) if fid <= B.HZ else (0, 1)
+        for lvl in levels:
+            amp = scale * (1e-12 if B.DX <= fid <= B.DZ else (1e-3 if fid <= B.HZ else 1.0))
+            data = (rng.standard_normal(s.shape) * amp).astype(np.float32)
+            s.set_field(fid, data, lvl)
+            o.set_field(fid, data, lvl)
+
+
+class Peak:
+    """Running max |oracle| per field, the denominator of the tolerance."""
+
+    def __init__(self):
+        self.peak = {}
+
+    def update(self, o, fids):
+        for fid in fids:
+            v = float(np.max(np.abs(o.field(fid)))) if np.all(np.isfinite(o.field(fid))) else np.inf
+            self.peak[fid] = max(self.peak.get(fid, 0.0), v)
+
+
+def compare(s, o, peak, where=""):
+    """Assert the tolerance contract; return the number of cells that are not
+    bit-identical (0 expected: both sides evaluate the same IEEE operations)."""
+    notbit = 0
+    for fid in fields_of(s):
+        got, want = s.field(fid), np.asarray(o.field(fid))
+        assert got.shape == want.shape
+        pk = peak.peak.get(fid, 0.0)
+        err = float(np.max(np.abs(got.astype(np.float64) - want.astype(np.float64))))
+        assert err <= TOL * pk or err == 0.0, \
+            f"{where} field {B.FIELD_NAMES[fid]}: max|diff| {err:.3e} > {TOL} * peak {pk:.3e}"
+        notbit += int(np.count_nonzero(got.view(np.uint32) != want.view(np.uint32)))
+    return notbit
+
+
+def run_and_compare(s, o, steps, check_every, where=""):
+    peak = Peak()
+    fids = fields_of(s)
+    done, notbit = 0, 0
+    while done < steps:
+        n = min(check_every, steps - done)
+        for _ in range(n):          # the peak is tracked every step
+            o.step(1, threads=4)
+            peak.update(o, fids)
+        s.step(n)
+        done += n
+        notbit += compare(s, o, peak, f"{where} step {done}")
+    return notbit

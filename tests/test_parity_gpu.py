@@ -252,6 +252,7 @@ def test_create_rejects_bad_inputs():
 
 # ------------------------------------------------------------------ full size
 
+@pytest.mark.timeout(600)
 def test_2d_full_size_16384_window_and_causality(oracle):
     """16384 x 16384 vacuum + centre source (the benchmark workload), 200 steps.
     Translation invariance: until the wave meets a boundary the solution only

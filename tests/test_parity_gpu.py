@@ -57,7 +57,7 @@ def test_3d_random_state_debye_and_mur(oracle, dims, ecoef):
         rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
         s.set_rp(face, rp)
         o.set_rp(face, rp)
-    util.randomize(s, o, rng)
+    util.randomize(s, o, rng, oracle)
     assert util.run_and_compare(s, o, 12, 3, f"{dims}") == 0
 
 
@@ -114,7 +114,7 @@ def test_2d_random_state_debye_and_mur(oracle, kernel, dims, chunk):
         rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
         s.set_rp(face, rp)
         o.set_rp(face, rp)
-    util.randomize(s, o, rng)
+    util.randomize(s, o, rng, oracle)
     assert util.run_and_compare(s, o, 15, 5, f"2-D random {dims}") == 0
 
 

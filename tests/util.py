@@ -41,13 +41,34 @@ def set_materials(s, o, codes, table=RIKEN_LIKE):
     o.set_materials(codes, table)
 
 
-def randomize(s, o, rng, scale=1.0):
-    """Same random state in both: H, and both time levels of D and E."""
+def written_masks(oracle_mod, o):
+    """Cells of D and E that a step writes, found by stepping a scratch oracle
+    whose target buffers hold a sentinel."""
+    scratch = oracle_mod.Oracle(o.p, ecoef=oracle_mod.ECOEF_CONSISTENT)
+    fids = [f for f in (fields_of_oracle(o)) if f > B.HZ]
+    for fid in fids:
+        scratch.field(fid, 2)[...] = 12345.0      # level 2 = the buffer the first step writes
+    scratch.step(1)
+    return {fid: np.asarray(scratch.field(fid)) != 12345.0 for fid in fids}
+
+
+def fields_of_oracle(o):
+    return [B.HX, B.HY, B.DZ, B.EZ] if o.p.nz == 1 else list(range(9))
+
+
+def randomize(s, o, rng, oracle_mod, scale=1.0):
+    """Same random state in both: H, and both time levels of D and E.  The
+    reference zeroes all three of its rotating buffers (fdtd.cu:1090-1118), so a
+    cell no kernel ever writes is zero at every time level; the random state
+    keeps that property (such cells stay zero)."""
+    masks = written_masks(oracle_mod, o)
     for fid in fields_of(s):
         levels = (0,) if fid <= B.HZ else (0, 1)
         for lvl in levels:
             amp = scale * (1e-12 if B.DX <= fid <= B.DZ else (1e-3 if fid <= B.HZ else 1.0))
             data = (rng.standard_normal(s.shape) * amp).astype(np.float32)
+            if fid in masks:
+                data = np.where(masks[fid], data, np.float32(0.0))     # +0.0, never -0.0
             s.set_field(fid, data, lvl)
             o.set_field(fid, data, lvl)
 

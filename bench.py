@@ -34,9 +34,9 @@ def cpu_baseline(nx, ny, budget_s=12.0):
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     p = oracle.make_params(nx, ny, 1, [(nx // 2, ny // 2, 0)])
     o = oracle.Oracle(p, ecoef=oracle.ECOEF_CONSISTENT)
-    o.step(2, threads)                                   # touch the pages
-    t_probe = o.time_steps(3, threads) / 3
-    steps = max(3, min(2000, int(budget_s / max(t_probe, 1e-6))))
+    o.step(10, threads)                                  # touch the pages, spin up the thread pool
+    t_probe = o.time_steps(20, threads) / 20
+    steps = max(3, min(5000, int(budget_s / max(t_probe, 1e-6))))
     sec = o.time_steps(steps, threads)
     return {
         "value": nx * ny * steps / sec / 1e6,

@@ -49,14 +49,16 @@ struct fdtd_ctx {
     int pitch = 0;
     size_t rows_store = 0; // storage rows per array (halo rows included)
     size_t elems = 0;      // floats per array without the slack
-    int chunk_rows = 64;
+    int chunk_rows = 1;
+    int variant = 1;
 
     std::vector<void *> allocs;
     float *h[3][2] = {};
     float *e[3][2] = {};
     float *d[3][2] = {};
     uint8_t *code = nullptr;
-    MatCoef *table = nullptr;
+    MatEntry *table = nullptr;
+    MatEntry table0 = {};
     float *rp[6] = {};
     size_t rp_n[6] = {};
 
@@ -65,7 +67,7 @@ struct fdtd_ctx {
     int64_t step = 0;
 
     MaterialRow mats[FDTD_MAX_CODES];
-    int ntab = FDTD_MAX_CODES;
+    int ntab = 1; // rows of the device table in use: 1 + (highest material code on the grid + 1)
     std::vector<uint8_t> codes_host; // slab cells, x fastest; empty = all default
     std::vector<float> rp_host[6];
     SourceList src; // global coordinates
@@ -125,6 +127,7 @@ Grid2D grid2d(const fdtd_ctx *c)
     g.gy0 = c->s0;
     g.gny = c->gn;
     g.pitch = c->pitch;
+    g.dt = p.dt;
     g.kh_x = p.dt / (p.mu0 * p.dx);
     g.kh_y = p.dt / (p.mu0 * p.dy);
     g.cx = p.dt / p.dx;
@@ -143,6 +146,7 @@ Grid3D grid3d(const fdtd_ctx *c)
     g.gz0 = c->s0;
     g.gnz = c->gn;
     g.pitch = c->pitch;
+    g.dt = p.dt;
     g.kh_x = p.dt / (p.mu0 * p.dx);
     g.kh_y = p.dt / (p.mu0 * p.dy);
     g.kh_z = p.dt / (p.mu0 * p.dz);
@@ -162,11 +166,20 @@ SourceList sources_for_step(const fdtd_ctx *c)
     return s;
 }
 
+// On the device a cell holds 0 for the default material and code + 1 for a
+// material code of the spec table, so that a grid without loaded materials
+// needs one table row and a loaded one only as many rows as it has codes.
+inline uint8_t device_code(uint8_t code) { return code == kDefaultCode ? 0 : (uint8_t)(code + 1); }
+
 int upload_table(fdtd_ctx *c)
 {
-    std::vector<MatCoef> t(FDTD_MAX_CODES);
-    for (int i = 0; i < FDTD_MAX_CODES; ++i) t[i] = make_coef(c->mats[i], c->p.dt, c->p.eps0, c->ecoef);
-    HIPCHK(hipMemcpyAsync(c->table, t.data(), t.size() * sizeof(MatCoef), hipMemcpyHostToDevice, c->stream));
+    std::vector<MatEntry> t(FDTD_MAX_CODES);
+    for (int i = 0; i < FDTD_MAX_CODES; ++i) {
+        const MatCoef k = make_coef(c->mats[i], c->p.dt, c->p.eps0, c->ecoef);
+        t[device_code((uint8_t)i)] = {k.a, k.c, k.d, c->mats[i].tau_d};
+    }
+    c->table0 = t[0];
+    HIPCHK(hipMemcpyAsync(c->table, t.data(), t.size() * sizeof(MatEntry), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -218,8 +231,14 @@ int upload_codes(fdtd_ctx *c)
     // owned rows only; halo rows keep the default code (their E is never updated here)
     const size_t rows = c->is2d() ? (size_t)c->sn : (size_t)c->sn * c->ny;
     uint8_t *dst = c->code + (c->is2d() ? (size_t)c->pitch : (size_t)c->ny * c->pitch);
-    HIPCHK(hipMemcpy2DAsync(dst, c->pitch, c->codes_host.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice,
-                            c->stream));
+    std::vector<uint8_t> dev(c->codes_host.size());
+    int top = 0;
+    for (size_t i = 0; i < dev.size(); ++i) {
+        dev[i] = device_code(c->codes_host[i]);
+        top = std::max(top, (int)dev[i]);
+    }
+    c->ntab = top + 1;
+    HIPCHK(hipMemcpy2DAsync(dst, c->pitch, dev.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -279,7 +298,9 @@ int step_once(fdtd_ctx *c)
         a.code = c->code;
         a.table = c->table;
         a.ntab = c->ntab;
+        a.one = c->table0;
         a.chunk_rows = c->chunk_rows;
+        a.variant = c->variant;
         a.src = sources_for_step(c);
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
         if (c->kernel == FDTD_KERNEL_FUSED) {
@@ -451,7 +472,8 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         set_error("slab must hold at least 2 rows inside the grid");
         return -3;
     }
-    c->chunk_rows = opt->chunk_rows > 0 ? opt->chunk_rows : 64;
+    c->chunk_rows = opt->chunk_rows > 0 ? opt->chunk_rows : 1;
+    if (const char *v = std::getenv("FDTD_SWEEP_VARIANT")) c->variant = std::atoi(v);
     if (p->sources_count < 0 || p->sources_count > FDTD_MAX_SOURCES) {
         set_error("too many sources");
         return -3;
@@ -500,7 +522,6 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     uint8_t *code_base = nullptr;
     if ((rc = dev_alloc(c, &code_base, c->elems + 2 * kSlack))) return rc;
     c->code = code_base + kSlack;
-    launch_fill_u8(code_base, c->elems + 2 * kSlack, (uint8_t)kDefaultCode, c->stream);
     if ((rc = dev_alloc(c, &c->table, (size_t)FDTD_MAX_CODES))) return rc;
 
     // Every code maps to the defaults until a spec table is loaded.

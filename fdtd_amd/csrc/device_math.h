@@ -1,0 +1,47 @@
+// Device-side arithmetic shared by the HIP kernels.  Evaluation order and the
+// fp32/fp64 mix follow the reference; everything is compiled with
+// -ffp-contract=off.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "internal.h"
+
+namespace fdtd {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// E^{n+1} of one cell, fdtd_calculations.cu:150-156:
+//   c * ( d*E^n - a*E^{n-1}                                   [fp32]
+//         + 2(dt+tau)*D^{n+1} - (2dt+4tau)*D^n + 2tau*D^{n-1} [fp64] )
+// The three fp64 factors are rebuilt from dt and tau exactly as the reference
+// builds them (dt + tau in fp32, the rest in fp64; doubling is exact).
+__device__ __forceinline__ float e_update(const MatEntry &m, float dt, float e0, float e1, float d0,
+                                          float d1, float d2)
+{
+    const float f = m.d * e0 - m.a * e1;
+    const double k1 = 2.0 * (double)(dt + m.tau);
+    const double k2 = 2.0 * (double)dt + 4.0 * (double)m.tau;
+    const double k3 = 2.0 * (double)m.tau;
+    double acc = (double)f + k1 * (double)d0;
+    acc = acc - k2 * (double)d1;
+    acc = acc + k3 * (double)d2;
+    return (float)((double)m.c * acc);
+}
+
+// First-order Mur face value, fdtd_calculations.cu:240-248 and its siblings.
+// r_here: rp on the face layer, r_in: rp on the first interior layer.
+__device__ __forceinline__ float mur_face(float dt, float du, float mu0, float eps0, float r_here,
+                                          float r_in, float et_in, float es_in, float es_here)
+{
+    const float s_here = du * sqrtf(mu0 * eps0 * r_here);
+    const float s_in = du * sqrtf(mu0 * eps0 * r_in);
+    return 1.0f / (dt + s_here) * ((dt - s_in) * et_in + (dt + s_in) * es_in - (dt - s_here) * es_here);
+}
+
+// The field arrays are streamed once per step and are far larger than the
+// caches: their loads and stores carry the nontemporal hint.
+__device__ __forceinline__ f4 ld4_stream(const float *p) { return __builtin_nontemporal_load((const f4 *)p); }
+__device__ __forceinline__ void st4_stream(float *p, f4 v) { __builtin_nontemporal_store(v, (f4 *)p); }
+
+} // namespace fdtd

@@ -26,6 +26,11 @@ struct alignas(16) MatCoef {
 };
 static_assert(sizeof(MatCoef) == 48, "MatCoef is read as three 16-byte LDS words");
 
+// What the kernels need of a MatCoef: 16 bytes per material code.
+struct alignas(16) MatEntry {
+    float a, c, d, tau;
+};
+
 struct MaterialRow {
     float sigma, eps_s, eps_inf, tau_d;
 };
@@ -47,6 +52,7 @@ struct ProbeList {
 // halo rows (zero outside the grid).  Every pointer addresses storage row 0.
 struct Grid2D {
     int nx, nyl, gy0, gny, pitch;
+    float dt;
     float kh_x, kh_y; // dt/(mu0*dx), dt/(mu0*dy)   (fdtd_calculations.cu:49,63)
     float cx, cy;     // dt/dx, dt/dy               (fdtd_calculations.cu:92-93)
     int has_lower;    // a neighbour slab exists below (gy0 > 0)
@@ -61,9 +67,11 @@ struct Sweep2D {
     const float *hx_r, *hy_r; // H read generation
     float *hx_w, *hy_w;       // H write generation (== read generation for the split kernels)
     const uint8_t *code;
-    const MatCoef *table;
+    const MatEntry *table;
+    MatEntry one;   // table[0], used when the grid holds a single material (ntab == 1)
     int ntab;
     int chunk_rows;
+    int variant;    // tuning switch: bit 0 = nontemporal hint on the last touch of re-read lines
     SourceList src;
 };
 
@@ -80,6 +88,7 @@ struct Mur2D {
 // local plane k = q - 1 (global gz0 + k); planes k = -1 and k = nzl are halos.
 struct Grid3D {
     int nx, ny, nzl, gz0, gnz, pitch;
+    float dt;
     float kh_x, kh_y, kh_z;
     float cx, cy, cz;
     int has_lower;
@@ -93,7 +102,7 @@ struct Sweep3D {
     float *d_w[3];
     float *h[3];
     const uint8_t *code;
-    const MatCoef *table;
+    const MatEntry *table;
     SourceList src;
 };
 
@@ -131,7 +140,6 @@ void launch_de3d(const Sweep3D &a, void *stream);
 void launch_mur3d(const Mur3D &a, void *stream);
 void launch_probe2d(const Probe2D &a, void *stream);
 void launch_probe3d(const Probe3D &a, void *stream);
-void launch_fill_u8(uint8_t *p, size_t n, uint8_t v, void *stream);
 const char *sweep2d_kernel_name();
 const char *de3d_kernel_name();
 const char *de2d_kernel_name();

@@ -1,9 +1,6 @@
 // HIP kernels of the FDTD field-update path for gfx950 (MI355X).
 //
 // What each kernel replaces in the reference (UnalignedByte/fdtd):
-//   fdtd2d_sweep : updateHField + updateDField + updateSources + updateEField
-//                  (fdtd_calculations.cu:32-213) for the 2-D TMz reduction, one
-//                  pass over memory per time step
 //   fdtd2d_h, fdtd2d_de, fdtd3d_h, fdtd3d_de : the same equations as an H
 //                  kernel and a fused D+source+E kernel
 //   fdtd2d_mur, fdtd3d_mur : updateMurBoundary (fdtd_calculations.cu:216-428)
@@ -12,38 +9,12 @@
 // is compiled with -ffp-contract=off, so results are bit-comparable with a
 // host build of the same equations.  The kernels are bandwidth bound (about
 // 0.5 flop per byte): no MFMA, wide coalesced loads, neighbours through lane
-// shuffles, the material table in LDS.
-#include <hip/hip_runtime.h>
-
-#include "internal.h"
+// shuffles.  The fused 2-D sweep lives in sweep2d.hip.
+#include "device_math.h"
 
 namespace fdtd {
 
 namespace {
-
-typedef float f4 __attribute__((ext_vector_type(4)));
-
-// E^{n+1} of one cell, fdtd_calculations.cu:150-156:
-//   c * ( d*E^n - a*E^{n-1}  [fp32]  + 2(dt+tau)*D^{n+1} - (2dt+4tau)*D^n + 2tau*D^{n-1}  [fp64] )
-__device__ __forceinline__ float e_update(const MatCoef &m, float e0, float e1, float d0, float d1,
-                                          float d2)
-{
-    const float f = m.d * e0 - m.a * e1;
-    double acc = (double)f + m.k1 * (double)d0;
-    acc = acc - m.k2 * (double)d1;
-    acc = acc + m.k3 * (double)d2;
-    return (float)((double)m.c * acc);
-}
-
-// First-order Mur face value, fdtd_calculations.cu:240-248 and its siblings.
-// r_here: rp on the face layer, r_in: rp on the first interior layer.
-__device__ __forceinline__ float mur_face(float dt, float du, float mu0, float eps0, float r_here,
-                                          float r_in, float et_in, float es_in, float es_here)
-{
-    const float s_here = du * sqrtf(mu0 * eps0 * r_here);
-    const float s_in = du * sqrtf(mu0 * eps0 * r_in);
-    return 1.0f / (dt + s_here) * ((dt - s_in) * et_in + (dt + s_in) * es_in - (dt - s_here) * es_here);
-}
 
 __device__ __forceinline__ bool is_source2d(const SourceList &s, int x, int gy)
 {
@@ -98,135 +69,8 @@ __global__ __launch_bounds__(256) void fdtd2d_de(const Sweep2D a)
         a.dz_w[o] = dn;
     }
     if (x >= 1) {
-        const MatCoef m = a.table[a.code[o]];
-        a.ez_w[o] = e_update(m, a.ez_n[o], a.ez_w[o], dn, d0, d1);
-    }
-}
-
-// ------------------------------------------------------------------ 2-D fused
-//
-// One pass per time step.  A wave owns a strip of 256 columns (lane l holds
-// columns 4l..4l+3 as one 16-byte word per array) and marches `chunk_rows`
-// rows in y.  The row above (ez^n) and the previous row's new hx stay in
-// registers, x neighbours come from the adjacent lane, and the two strip-edge
-// values (ez^n to the right, new hy to the left) are fetched or recomputed by
-// the edge lanes.  H is read from one generation and written to the other, so
-// recomputing a neighbour's H value never races with that neighbour's store.
-// Per cell this moves hx, hy, ez^n, ez^{n-1}, dz^n, dz^{n-1} (24 B) + 1 B code
-// in and hx, hy, ez^{n+1}, dz^{n+1} (16 B) out.
-__global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a)
-{
-    __shared__ MatCoef tab[FDTD_MAX_CODES];
-    for (int i = threadIdx.x; i < a.ntab; i += 256) tab[i] = a.table[i];
-    __syncthreads();
-
-    const Grid2D &g = a.g;
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int xw0 = ((int)blockIdx.x * 4 + wave) * 256;
-    if (xw0 >= g.nx) return;
-    const int x4 = xw0 + lane * 4;
-    const bool act = x4 < g.nx;
-    const int j0 = (int)blockIdx.y * a.chunk_rows;
-    const int j1 = min(j0 + a.chunk_rows, g.nyl);
-    const size_t pitch = (size_t)g.pitch;
-
-    // x guards of the four columns held by this lane
-    bool m_hx[4], m_hy[4], m_ez[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int x = x4 + i;
-        m_hx[i] = x >= 1 && x <= g.nx - 2;          // also the dz guard
-        m_hy[i] = x <= g.nx - 2;
-        m_ez[i] = x >= 1 && x <= g.nx - 1;
-    }
-    const bool edge_r = (lane == 63) && (xw0 + 256 < g.nx);
-    const bool edge_l = (lane == 0) && (xw0 > 0);
-
-    // sources that fall into this wave's strip and rows (wave-uniform mask)
-    unsigned srcmask = 0;
-    for (int s = 0; s < a.src.count; ++s) {
-        const int js = a.src.y[s] - g.gy0;
-        if (a.src.x[s] >= xw0 && a.src.x[s] < xw0 + 256 && js >= j0 && js < j1) srcmask |= 1u << s;
-    }
-
-    const f4 zero = {0.f, 0.f, 0.f, 0.f};
-    size_t off = (size_t)(j0 + 1) * pitch + x4;
-
-    // Prologue: new hx of row j0 - 1 (owned by the chunk below, or the halo row).
-    f4 ezc = act ? *(const f4 *)(a.ez_n + off) : zero;
-    f4 hxp = act ? *(const f4 *)(a.hx_r + off - pitch) : zero;
-    {
-        const f4 ezm = act ? *(const f4 *)(a.ez_n + off - pitch) : zero;
-        const int y = g.gy0 + j0 - 1;
-        if (y >= 0 && y <= g.gny - 2) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (m_hx[i]) hxp[i] = hxp[i] - g.kh_y * (ezc[i] - ezm[i]);
-        }
-        if (j0 == 0 && g.has_lower && act) *(f4 *)(a.hx_w + off - pitch) = hxp;
-    }
-
-    for (int j = j0; j < j1; ++j, off += pitch) {
-        const int y = g.gy0 + j;
-        const f4 ezn = act ? *(const f4 *)(a.ez_n + off + pitch) : zero;
-        const f4 hxo = act ? *(const f4 *)(a.hx_r + off) : zero;
-        const f4 hyo = act ? *(const f4 *)(a.hy_r + off) : zero;
-        const f4 e1 = act ? *(const f4 *)(a.ez_w + off) : zero;
-        const f4 d0 = act ? *(const f4 *)(a.dz_n + off) : zero;
-        const f4 d1 = act ? *(const f4 *)(a.dz_w + off) : zero;
-        const unsigned cd = act ? *(const unsigned *)(a.code + off) : 0u;
-
-        float e_right = __shfl_down(ezc.x, 1);
-        if (lane == 63) e_right = edge_r ? a.ez_n[off + 4] : 0.f;
-        float hy_lo = 0.f, ez_lo = 0.f;
-        if (edge_l) {
-            hy_lo = a.hy_r[off - 1];
-            ez_lo = a.ez_n[off - 1];
-        }
-
-        const bool gy_hx = y <= g.gny - 2;
-        const bool gy_in = y >= 1 && y <= g.gny - 2;
-
-        f4 hxn, hyn;
-        const float er[4] = {ezc.y, ezc.z, ezc.w, e_right};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            hxn[i] = (gy_hx && m_hx[i]) ? hxo[i] - g.kh_y * (ezn[i] - ezc[i]) : hxo[i];
-            hyn[i] = (gy_in && m_hy[i]) ? hyo[i] + g.kh_x * (er[i] - ezc[i]) : hyo[i];
-        }
-        float hy_left = __shfl_up(hyn.w, 1);
-        if (lane == 0) hy_left = (edge_l && gy_in) ? hy_lo + g.kh_x * (ezc.x - ez_lo) : hy_lo;
-        const float hl[4] = {hy_left, hyn.x, hyn.y, hyn.z};
-
-        unsigned srcflag = 0;
-        if (srcmask) {
-            for (int s = 0; s < a.src.count; ++s) {
-                if (!((srcmask >> s) & 1u) || a.src.y[s] - g.gy0 != j) continue;
-                const int rel = a.src.x[s] - xw0;
-                if ((rel >> 2) == lane) srcflag |= 1u << (rel & 3);
-            }
-        }
-
-        f4 dzn, ezw;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float v = (d0[i] + g.cx * (hyn[i] - hl[i])) - g.cy * (hxn[i] - hxp[i]);
-            float dn = (gy_in && m_hx[i]) ? v : d1[i];
-            if ((srcflag >> i) & 1u) dn = v - a.src.jz;
-            dzn[i] = dn;
-            const MatCoef &m = tab[(cd >> (8 * i)) & 0xffu];
-            ezw[i] = m_ez[i] ? e_update(m, ezc[i], e1[i], dn, d0[i], d1[i]) : e1[i];
-        }
-
-        if (act) {
-            *(f4 *)(a.hx_w + off) = hxn;
-            *(f4 *)(a.hy_w + off) = hyn;
-            *(f4 *)(a.dz_w + off) = dzn;
-            *(f4 *)(a.ez_w + off) = ezw;
-        }
-        hxp = hxn;
-        ezc = ezn;
+        const MatEntry m = a.table[a.code[o]];
+        a.ez_w[o] = e_update(m, g.dt, a.ez_n[o], a.ez_w[o], dn, d0, d1);
     }
 }
 
@@ -334,11 +178,11 @@ __global__ __launch_bounds__(256) void fdtd3d_de(const Sweep3D a)
     const bool g_ex = x_in && y_lo && y_in && z_lo && z_in;
     const bool g_eyz = x_lo && z_lo;
     if (g_ex || g_eyz) {
-        const MatCoef m = a.table[a.code[o]];
-        if (g_ex) a.e_w[0][o] = e_update(m, a.e_n[0][o], a.e_w[0][o], dn[0], d0[0], d1[0]);
+        const MatEntry m = a.table[a.code[o]];
+        if (g_ex) a.e_w[0][o] = e_update(m, g.dt, a.e_n[0][o], a.e_w[0][o], dn[0], d0[0], d1[0]);
         if (g_eyz) {
-            a.e_w[1][o] = e_update(m, a.e_n[1][o], a.e_w[1][o], dn[1], d0[1], d1[1]);
-            a.e_w[2][o] = e_update(m, a.e_n[2][o], a.e_w[2][o], dn[2], d0[2], d1[2]);
+            a.e_w[1][o] = e_update(m, g.dt, a.e_n[1][o], a.e_w[1][o], dn[1], d0[1], d1[1]);
+            a.e_w[2][o] = e_update(m, g.dt, a.e_n[2][o], a.e_w[2][o], dn[2], d0[2], d1[2]);
         }
     }
 }
@@ -444,12 +288,6 @@ __global__ void fdtd3d_probe(const Probe3D a)
     for (int c = 0; c < 9; ++c) dst[c] = in ? a.f[c][o] : 0.f;
 }
 
-__global__ void fill_u8_kernel(uint8_t *p, size_t n, uint8_t v)
-{
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
-}
-
 } // namespace
 
 // ------------------------------------------------------------------ launchers
@@ -468,13 +306,6 @@ void launch_de2d(const Sweep2D &a, void *stream)
 {
     dim3 grid((a.g.nx + 255) / 256, a.g.nyl, 1);
     hipLaunchKernelGGL(fdtd2d_de, grid, dim3(256), 0, S(stream), a);
-}
-
-void launch_sweep2d(const Sweep2D &a, void *stream)
-{
-    const int chunks = (a.g.nyl + a.chunk_rows - 1) / a.chunk_rows;
-    dim3 grid((a.g.nx + 1023) / 1024, chunks, 1);
-    hipLaunchKernelGGL(fdtd2d_sweep, grid, dim3(256), 0, S(stream), a);
 }
 
 void launch_mur2d(const Mur2D &a, void *stream)
@@ -511,12 +342,6 @@ void launch_probe3d(const Probe3D &a, void *stream)
     hipLaunchKernelGGL(fdtd3d_probe, dim3(1), dim3(64), 0, S(stream), a);
 }
 
-void launch_fill_u8(uint8_t *p, size_t n, uint8_t v, void *stream)
-{
-    hipLaunchKernelGGL(fill_u8_kernel, dim3(2048), dim3(256), 0, S(stream), p, n, v);
-}
-
-const char *sweep2d_kernel_name() { return "fdtd2d_sweep"; }
 const char *de2d_kernel_name() { return "fdtd2d_de"; }
 const char *de3d_kernel_name() { return "fdtd3d_de"; }
 

@@ -86,6 +86,7 @@ SYMBOLS = [
     ("fdtd_halo_put", _I, [_VP, _I, _VP, _SZ]),
     ("fdtd_comm_unique_id", _I, [C.c_char_p]),
     ("fdtd_comm_init", _I, [_VP, C.c_char_p, _I, _I]),
+    ("fdtd_comm_selftest", _I, [_VP]),
 ]
 
 _lib = None
@@ -297,6 +298,9 @@ class Solver:
 
     def comm_init(self, unique_id, rank, world):
         _check(self.lib.fdtd_comm_init(self._ctx, unique_id, rank, world))
+
+    def comm_selftest(self):
+        _check(self.lib.fdtd_comm_selftest(self._ctx))
 
 
 def comm_unique_id():

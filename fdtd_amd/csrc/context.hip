@@ -901,8 +901,33 @@ int fdtd_comm_init(fdtd_ctx *c, const char id[128], int rank, int world)
     }
     c->rank = rank;
     c->world = world;
-    if (world == 1) return 0;
     return comm_create(id, rank, world, &c->comm);
+}
+
+int fdtd_comm_selftest(fdtd_ctx *c)
+{
+    if (!c->comm) {
+        set_error("fdtd_comm_selftest: call fdtd_comm_init first");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    // first owned row of the newest E level -> upper halo row, through ncclSend/ncclRecv to this rank
+    const int comp = 2;
+    const size_t count = c->is2d() ? (size_t)c->nx : (size_t)c->ny * c->pitch;
+    int rc = comm_group_start(c->comm);
+    if (!rc) rc = comm_send(c->comm, halo_rows(c, comp, 0, false), count, c->rank, c->stream);
+    if (!rc) rc = comm_recv(c->comm, halo_rows(c, comp, 1, true), count, c->rank, c->stream);
+    const int rc2 = comm_group_end(c->comm);
+    if (rc || rc2) return rc ? rc : rc2;
+    std::vector<float> a(count), b(count);
+    HIPCHK(hipMemcpyAsync(a.data(), halo_rows(c, comp, 0, false), count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(b.data(), halo_rows(c, comp, 1, true), count * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (std::memcmp(a.data(), b.data(), count * 4) != 0) {
+        set_error("fdtd_comm_selftest: the received row differs from the row sent");
+        return -22;
+    }
+    return 0;
 }
 
 } // extern "C"

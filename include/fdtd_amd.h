@@ -199,6 +199,10 @@ int fdtd_halo_put(fdtd_ctx *ctx, int side, const float *src, size_t count);
  * on the context's stream.  The slab of rank r must be the r-th slab. */
 int fdtd_comm_unique_id(char id[128]);
 int fdtd_comm_init(fdtd_ctx *ctx, const char id[128], int rank, int world);
+/* Diagnostic: sends the first owned ez row (3-D: ez plane) to this very rank
+ * through ncclSend/ncclRecv into the upper halo and checks that it arrived.
+ * Usable with a one-rank communicator; overwrites the upper halo. */
+int fdtd_comm_selftest(fdtd_ctx *ctx);
 
 #ifdef __cplusplus
 }

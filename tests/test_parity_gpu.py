@@ -211,6 +211,39 @@ def test_3d_slabs_equal_whole_grid(oracle):
     assert np.abs(whole.field(B.EX)).max() > 0
 
 
+def test_rccl_binding_with_a_one_rank_communicator():
+    """The RCCL entry points (dlopen, ncclCommInitRank, grouped ncclSend/ncclRecv on the
+    library's stream) on one GPU: a one-rank communicator sends a row to itself."""
+    s = fdtd_amd.Solver(fdtd_amd.make_params(700, 40, 1, [(350, 20, 0)]), ecoef=CON, slab=(0, 40))
+    s.step(30)
+    s.comm_init(B.comm_unique_id(), 0, 1)
+    s.comm_selftest()
+    assert np.array_equal(s.halo_get(0), s.field(B.EZ)[0, 0])
+    s.step(5)                      # stepping with a communicator and no neighbours is a no-op exchange
+    s3 = fdtd_amd.Solver(fdtd_amd.make_params(40, 30, 20, [(20, 15, 10)]), ecoef=CON)
+    s3.step(20)
+    s3.comm_init(B.comm_unique_id(), 0, 1)
+    s3.comm_selftest()
+
+
+@pytest.mark.timeout(300)
+def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path):
+    """Two ranks (two processes, both on GPU 0) run the slab protocol with the HIP engine
+    and gloo-staged halos; the joined result equals the oracle bit for bit."""
+    import subprocess
+    import sys
+    nx, ny, steps = 1500, 200, 120
+    script = os.path.join(os.path.dirname(__file__), "slab_rank_main.py")
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", "29517", str(nx), str(ny), str(steps), str(tmp_path)])
+             for r in range(2)]
+    assert [p.wait(timeout=240) for p in procs] == [0, 0]
+    o = oracle.Oracle(oracle.make_params(nx, ny, 1, [(nx // 2, ny // 2, 0), (10, ny // 2 - 1, 0)]), ecoef=CON)
+    o.step(steps, threads=4)
+    for fid in (B.HX, B.HY, B.DZ, B.EZ):
+        got = np.concatenate([np.load(tmp_path / f"f{fid}_r{r}.npy") for r in range(2)], axis=0)
+        assert np.array_equal(got.view(np.uint32), np.asarray(o.field(fid)[0]).view(np.uint32)), B.FIELD_NAMES[fid]
+
+
 # ------------------------------------------------------------------ results path
 
 def test_probes_and_snapshot_agree_with_read_field(oracle):

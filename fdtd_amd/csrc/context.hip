@@ -51,6 +51,7 @@ struct fdtd_ctx {
     size_t elems = 0;      // floats per array without the slack
     int chunk_rows = 1;
     int variant = 1;
+    int band = 32, nopad = 0;
 
     std::vector<void *> allocs;
     float *h[3][2] = {};
@@ -301,6 +302,8 @@ int step_once(fdtd_ctx *c)
         a.one = c->table0;
         a.chunk_rows = c->chunk_rows;
         a.variant = c->variant;
+        a.band = c->band;
+        a.nopad = c->nopad;
         a.src = sources_for_step(c);
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
         if (c->kernel == FDTD_KERNEL_FUSED) {
@@ -474,6 +477,8 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     }
     c->chunk_rows = opt->chunk_rows > 0 ? opt->chunk_rows : 1;
     if (const char *v = std::getenv("FDTD_SWEEP_VARIANT")) c->variant = std::atoi(v);
+    if (const char *v = std::getenv("FDTD_SWEEP_BAND")) c->band = std::atoi(v) / 8 * 8;
+    if (const char *v = std::getenv("FDTD_SWEEP_NOPAD")) c->nopad = std::atoi(v);
     if (p->sources_count < 0 || p->sources_count > FDTD_MAX_SOURCES) {
         set_error("too many sources");
         return -3;

@@ -72,6 +72,8 @@ struct Sweep2D {
     int ntab;
     int chunk_rows;
     int variant;    // tuning switch: bit 0 = nontemporal hint on the last touch of re-read lines
+    int band;       // block order: 0 = row-major, else rows per band (multiple of 8)
+    int nopad;      // row-major order without padding the x block count to a multiple of 8
     SourceList src;
 };
 

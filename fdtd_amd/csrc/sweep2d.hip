@@ -68,15 +68,37 @@ __device__ __forceinline__ void load_row(Row2D &r, const Sweep2D &a, size_t off,
     r.ez_lo = edge_l ? a.ez_n[off - 1] : 0.f;
 }
 
+// How block ids map to (x block, row chunk).
+struct BlockMap {
+    int xblocks; // x blocks of 1024 columns that hold cells
+    int xpad;    // row-major order: x blocks per row of blocks, padded
+    int band;    // 0 = row-major order; else rows of blocks per band (a multiple of 8)
+    int chunks;  // row chunks in all
+};
+
 // ONE: the whole grid is one material; its coefficients are a kernel argument.
 template <bool ONE, int POL>
-__global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const int xblocks)
+__global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const BlockMap m)
 {
     const Grid2D &g = a.g;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int xb = (int)(blockIdx.x % (unsigned)xblocks);
-    const int chunk = (int)(blockIdx.x / (unsigned)xblocks);
+    int xb, chunk;
+    if (m.band == 0) {
+        xb = (int)(blockIdx.x % (unsigned)m.xpad);
+        chunk = (int)(blockIdx.x / (unsigned)m.xpad);
+        if (xb >= m.xblocks) return;
+    } else {
+        // Bands of `band` rows.  Inside a band the blocks are ordered column by column and
+        // cut into 8 equal runs; the hardware deals consecutive block ids to the 8 XCDs in
+        // turn, so XCD i walks run i: consecutive rows of one column, one after the other.
+        const unsigned per_band = (unsigned)m.band * (unsigned)m.xblocks;
+        const unsigned s = blockIdx.x / per_band, bl = blockIdx.x % per_band;
+        const unsigned q = (bl & 7u) * (per_band >> 3) + (bl >> 3);
+        xb = (int)(q / (unsigned)m.band);
+        chunk = (int)(s * (unsigned)m.band + q % (unsigned)m.band);
+        if (chunk >= m.chunks) return;
+    }
     const int xw0 = (xb * 4 + wave) * 256;
     if (xw0 >= g.nx) return;
     const int x4 = xw0 + lane * 4;
@@ -208,9 +230,17 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const int x
 
 void launch_sweep2d(const Sweep2D &a, void *stream)
 {
-    const int chunks = (a.g.nyl + a.chunk_rows - 1) / a.chunk_rows;
-    const int xblocks = ((a.g.nx + 1023) / 1024 + 7) / 8 * 8;
-    const dim3 grid((unsigned)xblocks * (unsigned)chunks);
+    BlockMap xblocks;
+    xblocks.chunks = (a.g.nyl + a.chunk_rows - 1) / a.chunk_rows;
+    xblocks.xblocks = (a.g.nx + 1023) / 1024;
+    xblocks.xpad = a.nopad ? xblocks.xblocks : (xblocks.xblocks + 7) / 8 * 8;
+    xblocks.band = a.band;
+    unsigned nblocks;
+    if (a.band == 0)
+        nblocks = (unsigned)xblocks.xpad * (unsigned)xblocks.chunks;
+    else
+        nblocks = (unsigned)((xblocks.chunks + a.band - 1) / a.band) * (unsigned)a.band * (unsigned)xblocks.xblocks;
+    const dim3 grid(nblocks);
     const bool one = a.ntab == 1;
     if (a.variant & 1) {
         if (one)

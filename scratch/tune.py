@@ -6,9 +6,11 @@ import fdtd_amd
 from fdtd_amd import binding as B
 DATA = os.path.join(os.path.dirname(__file__), '..', 'data')
 
-def run(nx, ny, chunk, steps=40, warm=5, skew=0, variant=0, pgm=0):
+def run(nx, ny, chunk, steps=40, warm=5, skew=0, variant=0, pgm=0, band=0, nopad=0):
     os.environ["FDTD_PITCH_SKEW"] = str(skew)
     os.environ["FDTD_SWEEP_VARIANT"] = str(variant)
+    os.environ["FDTD_SWEEP_BAND"] = str(band)
+    os.environ["FDTD_SWEEP_NOPAD"] = str(nopad)
     p = fdtd_amd.make_params(nx, ny, 1, [(nx // 8, ny // 2, 0)])
     s = fdtd_amd.Solver(p, ecoef=B.ECOEF_CONSISTENT, chunk_rows=chunk)
     if pgm:
@@ -31,10 +33,14 @@ if __name__ == "__main__":
             nx = ny = 16384; pgm = 0
         elif cfg == "pgm":
             nx, ny, pgm = 265 * 32, 490 * 32, 32
+        elif cfg == "vac2":
+            nx, ny, pgm = 265 * 32, 490 * 32, 0
         elif cfg == "wide":
             nx, ny, pgm = 65536, 4096, 0
         cells = nx * ny
+        bands = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
         for variant in variants:
+          for band in bands:
             for chunk in chunks:
-                med, mean, wall, ok = run(nx, ny, chunk, variant=variant, pgm=pgm)
-                print(f"{cfg} {nx}x{ny} variant {variant} chunk {chunk:3d}: sweep median {med:.3f} ms mean {mean:.3f} wall/step {wall:.3f} ms -> {cells/med/1e6:.1f} Gcell/s, {cells * 41 / med / 1e6:.0f} GB/s algorithmic ({cells*41/med/1e6/80:.1f}% of 8 TB/s){ok}", flush=True)
+                med, mean, wall, ok = run(nx, ny, chunk, variant=variant, pgm=pgm, band=max(band, 0), nopad=1 if band < 0 else 0)
+                print(f"{cfg} {nx}x{ny} variant {variant} band {band} chunk {chunk:3d}: sweep median {med:.3f} ms mean {mean:.3f} wall/step {wall:.3f} ms -> {cells/med/1e6:.1f} Gcell/s, {cells * 41 / med / 1e6:.0f} GB/s algorithmic ({cells*41/med/1e6/80:.1f}% of 8 TB/s){ok}", flush=True)

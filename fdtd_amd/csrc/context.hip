@@ -348,8 +348,37 @@ int step_once(fdtd_ctx *c)
         a.table = c->table;
         a.src = sources_for_step(c);
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-        launch_h3d(a, c->stream);
-        launch_de3d(a, c->stream);
+        if (c->kernel == FDTD_KERNEL_FUSED) {
+            Fused3D f;
+            f.g = a.g;
+            for (int k = 0; k < 3; ++k) {
+                f.e_n[k] = a.e_n[k];
+                f.e_w[k] = a.e_w[k];
+                f.d_n[k] = a.d_n[k];
+                f.d_w[k] = a.d_w[k];
+                f.h_r[k] = c->h[k][c->hgen];
+                f.h_w[k] = c->h[k][c->hgen ^ 1];
+            }
+            f.code = c->code;
+            f.table = c->table;
+            f.one = c->table0;
+            f.ntab = c->ntab;
+            f.jz = a.src.jz;
+            f.nsrc = a.src.count;
+            const long long p4 = c->pitch / 4;
+            f.total4 = (long long)c->sn * c->ny * p4;
+            for (int s = 0; s < a.src.count; ++s) {
+                const int kz = a.src.z[s] - c->s0;
+                const bool here = kz >= 0 && kz < c->sn;
+                f.src_word[s] = here ? ((long long)kz * c->ny + a.src.y[s]) * p4 + a.src.x[s] / 4 : -1;
+                f.src_comp[s] = a.src.x[s] % 4;
+            }
+            launch_sweep3d(f, c->stream);
+            c->hgen ^= 1;
+        } else {
+            launch_h3d(a, c->stream);
+            launch_de3d(a, c->stream);
+        }
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
         Mur3D m;
         m.g = a.g;
@@ -459,13 +488,9 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         return -3;
     }
     c->ecoef = opt->ecoef;
-    c->kernel = opt->kernel == FDTD_KERNEL_AUTO ? (c->is2d() ? FDTD_KERNEL_FUSED : FDTD_KERNEL_SPLIT) : opt->kernel;
+    c->kernel = opt->kernel == FDTD_KERNEL_AUTO ? FDTD_KERNEL_FUSED : opt->kernel;
     if (c->kernel != FDTD_KERNEL_SPLIT && c->kernel != FDTD_KERNEL_FUSED) {
         set_error("unknown kernel selection");
-        return -3;
-    }
-    if (c->kernel == FDTD_KERNEL_FUSED && !c->is2d()) {
-        set_error("the fused sweep exists for the 2-D TMz mode only");
         return -3;
     }
     c->gn = c->is2d() ? p->ny : p->nz;
@@ -735,7 +760,7 @@ int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
 const char *fdtd_sweep_kernel_name(const fdtd_ctx *c)
 {
     if (c->is2d()) return c->kernel == FDTD_KERNEL_FUSED ? sweep2d_kernel_name() : de2d_kernel_name();
-    return de3d_kernel_name();
+    return c->kernel == FDTD_KERNEL_FUSED ? sweep3d_kernel_name() : de3d_kernel_name();
 }
 
 int fdtd_read_field(fdtd_ctx *c, int field, int level, float *dst, size_t count)

@@ -116,6 +116,27 @@ struct Mur3D {
     float dt, dx, dy, dz, mu0, eps0;
 };
 
+// The fused 3-D sweep (sweep3d.hip): H read and write generations, sources as
+// word indices into the flat run of 16-byte words of the owned planes.
+struct Fused3D {
+    Grid3D g;
+    const float *e_n[3];
+    float *e_w[3];
+    const float *d_n[3];
+    float *d_w[3];
+    const float *h_r[3];
+    float *h_w[3];
+    const uint8_t *code;
+    const MatEntry *table;
+    MatEntry one;
+    int ntab;
+    int nsrc;
+    float jz;
+    long long total4;                      // 16-byte words of the owned planes: nzl * ny * pitch / 4
+    long long src_word[FDTD_MAX_SOURCES];  // word holding the source cell, -1 if another slab holds it
+    int src_comp[FDTD_MAX_SOURCES];        // which of the word's four cells
+};
+
 struct Probe2D {
     Grid2D g;
     const float *hx, *hy, *dz, *ez;
@@ -136,6 +157,7 @@ struct Probe3D {
 void launch_h2d(const Sweep2D &a, void *stream);
 void launch_de2d(const Sweep2D &a, void *stream);
 void launch_sweep2d(const Sweep2D &a, void *stream);
+void launch_sweep3d(const Fused3D &a, void *stream);
 void launch_mur2d(const Mur2D &a, void *stream);
 void launch_h3d(const Sweep3D &a, void *stream);
 void launch_de3d(const Sweep3D &a, void *stream);
@@ -143,6 +165,7 @@ void launch_mur3d(const Mur3D &a, void *stream);
 void launch_probe2d(const Probe2D &a, void *stream);
 void launch_probe3d(const Probe3D &a, void *stream);
 const char *sweep2d_kernel_name();
+const char *sweep3d_kernel_name();
 const char *de3d_kernel_name();
 const char *de2d_kernel_name();
 

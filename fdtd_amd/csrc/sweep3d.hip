@@ -1,0 +1,234 @@
+// fdtd3d_sweep: one pass over memory per time step of the 3-D grid --
+// updateHField + updateDField + updateSources + updateEField
+// (fdtd_calculations.cu:32-213) fused.
+//
+// Work decomposition.  The owned planes of a field are one flat run of 16-byte
+// words (rows of pitch/4 words, ny rows per plane); thread t owns word t, i.e.
+// four consecutive x cells of one (y, z) row, and a block owns 256 consecutive
+// words -- 4 KB of every array, the access pattern of a flat copy.  Blocks are
+// grouped in bands of 512 and dealt so that each XCD walks 64 consecutive blocks.
+//
+// Neighbours.  D^{n+1}(c) needs the NEW H at c and at c-x, c-y, c-z.  Those six
+// neighbour values are recomputed here from the old H and E^n of the
+// neighbouring rows (lines the blocks before this one have just pulled into
+// L2 / the Infinity Cache), the x neighbours come from the adjacent lane, and
+// the lanes at the ends of a wave fetch the few scalars they lack.  H is read
+// from one generation and written to the other, so a recomputed value never
+// races with its owner's store.
+//
+// Traffic per cell from HBM: 3 H + 3 E^n + 3 E^{n-1} + 3 D^n + 3 D^{n-1} in
+// (60 B) + 1 B material code, 3 H + 3 E^{n+1} + 3 D^{n+1} out (36 B) = 97 B.
+#include "device_math.h"
+
+namespace fdtd {
+
+namespace {
+
+__device__ __forceinline__ f4 ld4(const float *p, bool act, bool stream)
+{
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    if (!act) return zero;
+    return stream ? ld4_stream(p) : *(const f4 *)p;
+}
+
+// {v[1], v[2], v[3], first element of the next lane (or `edge` on lane 63)}
+__device__ __forceinline__ f4 shift_left(f4 v, int lane, float edge)
+{
+    float nxt = __shfl_down(v.x, 1);
+    if (lane == 63) nxt = edge;
+    const f4 r = {v.y, v.z, v.w, nxt};
+    return r;
+}
+
+// {last element of the previous lane (or `edge` on lane 0), v[0], v[1], v[2]}
+__device__ __forceinline__ f4 shift_right(f4 v, int lane, float edge)
+{
+    float prv = __shfl_up(v.w, 1);
+    if (lane == 0) prv = edge;
+    const f4 r = {prv, v.x, v.y, v.z};
+    return r;
+}
+
+template <bool ONE> __global__ __launch_bounds__(256) void fdtd3d_sweep(const Fused3D a)
+{
+    const Grid3D &g = a.g;
+    const int lane = threadIdx.x & 63;
+    // band order: 512 blocks per band, XCD i (block id mod 8) walks blocks [64 i, 64 i + 64) of the band
+    const unsigned bl = blockIdx.x & 511u;
+    const unsigned blk = (blockIdx.x & ~511u) + ((bl & 7u) << 6) + (bl >> 3);
+    const long long t = (long long)blk * 256 + threadIdx.x;
+
+    const int p4 = g.pitch >> 2;
+    const long long rowid = t / p4;
+    const int i4 = (int)(t - rowid * p4);
+    const int y = (int)(rowid % g.ny);
+    const int k = (int)(rowid / g.ny);
+    const int x4 = i4 * 4;
+    const bool act = t < a.total4 && x4 < g.nx;
+    const int z = g.gz0 + k;
+    const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
+    const size_t o = act ? (size_t)(k + 1) * ps + (size_t)y * rs + x4 : ps;
+
+    const float *ex = a.e_n[0], *ey = a.e_n[1], *ez = a.e_n[2];
+    const float *hx = a.h_r[0], *hy = a.h_r[1], *hz = a.h_r[2];
+
+    // E^n and old H: own row and the rows below in y and z (and the two diagonals)
+    const f4 ex_c = ld4(ex + o, act, false), ex_py = ld4(ex + o + rs, act, false), ex_pz = ld4(ex + o + ps, act, false);
+    const f4 ex_my = ld4(ex + o - rs, act, false), ex_mz = ld4(ex + o - ps, act, true);
+    const f4 ey_c = ld4(ey + o, act, false), ey_pz = ld4(ey + o + ps, act, false), ey_my = ld4(ey + o - rs, act, false);
+    const f4 ey_mypz = ld4(ey + o - rs + ps, act, false), ey_mz = ld4(ey + o - ps, act, true);
+    const f4 ez_c = ld4(ez + o, act, false), ez_py = ld4(ez + o + rs, act, false), ez_my = ld4(ez + o - rs, act, false);
+    const f4 ez_mz = ld4(ez + o - ps, act, true), ez_mzpy = ld4(ez + o - ps + rs, act, false);
+    const f4 hx_c = ld4(hx + o, act, false), hx_my = ld4(hx + o - rs, act, false), hx_mz = ld4(hx + o - ps, act, true);
+    const f4 hy_c = ld4(hy + o, act, false), hy_mz = ld4(hy + o - ps, act, true);
+    const f4 hz_c = ld4(hz + o, act, false), hz_my = ld4(hz + o - rs, act, true);
+    f4 d0[3], d1[3], e1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d0[c] = ld4(a.d_n[c] + o, act, true);
+        d1[c] = ld4(a.d_w[c] + o, act, true);
+        e1[c] = ld4(a.e_w[c] + o, act, true);
+    }
+    const unsigned cd = act ? *(const unsigned *)(a.code + o) : 0u;
+
+    // scalars the lanes at the two ends of the wave lack
+    const bool edge_r = (lane == 63) && act && (x4 + 4 < g.nx);
+    const bool edge_l = (lane == 0) && act && (x4 > 0);
+    float r_ez = 0.f, r_ey = 0.f, r_ey_my = 0.f, r_ez_mz = 0.f;
+    if (edge_r) {
+        r_ez = ez[o + 4];
+        r_ey = ey[o + 4];
+        r_ey_my = ey[o - rs + 4];
+        r_ez_mz = ez[o - ps + 4];
+    }
+    float l_hy = 0.f, l_hz = 0.f, l_ex = 0.f, l_ex_pz = 0.f, l_ex_py = 0.f, l_ez = 0.f, l_ey = 0.f;
+    if (edge_l) {
+        l_hy = hy[o - 1];
+        l_hz = hz[o - 1];
+        l_ex = ex[o - 1];
+        l_ex_pz = ex[o - 1 + ps];
+        l_ex_py = ex[o - 1 + rs];
+        l_ez = ez[o - 1];
+        l_ey = ey[o - 1];
+    }
+
+    // guards
+    bool x_lo[4], x_hi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x_lo[i] = x4 + i >= 1;
+        x_hi[i] = x4 + i <= g.nx - 2;
+    }
+    const bool y_lo = y >= 1, y_hi = y <= g.ny - 2, z_lo = z >= 1, z_hi = z <= g.gnz - 2;
+    const bool ym_lo = y - 1 >= 1, ym_ok = y - 1 >= 0;           // row y-1
+    const bool zm_lo = z - 1 >= 1, zm_ok = z - 1 >= 0;           // plane z-1
+
+    const f4 ez_px = shift_left(ez_c, lane, r_ez);
+    const f4 ey_px = shift_left(ey_c, lane, r_ey);
+    const f4 ey_my_px = shift_left(ey_my, lane, r_ey_my);
+    const f4 ez_mz_px = shift_left(ez_mz, lane, r_ez_mz);
+
+    f4 hx_n, hy_n, hz_n, hx_ny, hz_ny, hx_nz, hy_nz;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // own cell, fdtd_calculations.cu:44-76
+        hx_n[i] = (x_lo[i] && x_hi[i] && y_hi && z_hi)
+                      ? hx_c[i] - g.kh_y * (ez_py[i] - ez_c[i]) + g.kh_y * (ey_pz[i] - ey_c[i]) : hx_c[i];
+        hy_n[i] = (x_hi[i] && y_lo && y_hi && z_hi)
+                      ? hy_c[i] - g.kh_z * (ex_pz[i] - ex_c[i]) + g.kh_x * (ez_px[i] - ez_c[i]) : hy_c[i];
+        hz_n[i] = (x_hi[i] && y_hi && z_lo && z_hi)
+                      ? hz_c[i] - g.kh_x * (ey_px[i] - ey_c[i]) + g.kh_y * (ex_py[i] - ex_c[i]) : hz_c[i];
+        // row y-1 (its y+1 neighbour is this row): y-1 <= ny-2 always holds
+        hx_ny[i] = (x_lo[i] && x_hi[i] && ym_ok && z_hi)
+                       ? hx_my[i] - g.kh_y * (ez_c[i] - ez_my[i]) + g.kh_y * (ey_mypz[i] - ey_my[i]) : hx_my[i];
+        hz_ny[i] = (x_hi[i] && ym_ok && z_lo && z_hi)
+                       ? hz_my[i] - g.kh_x * (ey_my_px[i] - ey_my[i]) + g.kh_y * (ex_c[i] - ex_my[i]) : hz_my[i];
+        // plane z-1 (its z+1 neighbour is this plane): z-1 <= gnz-2 always holds
+        hx_nz[i] = (x_lo[i] && x_hi[i] && y_hi && zm_ok)
+                       ? hx_mz[i] - g.kh_y * (ez_mzpy[i] - ez_mz[i]) + g.kh_y * (ey_c[i] - ey_mz[i]) : hx_mz[i];
+        hy_nz[i] = (x_hi[i] && y_lo && y_hi && zm_ok)
+                       ? hy_mz[i] - g.kh_z * (ex_c[i] - ex_mz[i]) + g.kh_x * (ez_mz_px[i] - ez_mz[i]) : hy_mz[i];
+    }
+    (void)ym_lo;
+    (void)zm_lo;
+
+    // new hy, hz of the cell left of the wave (x4 - 1 <= nx-2 holds there)
+    float e_hy = l_hy, e_hz = l_hz;
+    if (edge_l) {
+        if (y_lo && y_hi && z_hi) e_hy = l_hy - g.kh_z * (l_ex_pz - l_ex) + g.kh_x * (ez_c.x - l_ez);
+        if (y_hi && z_lo && z_hi) e_hz = l_hz - g.kh_x * (ey_c.x - l_ey) + g.kh_y * (l_ex_py - l_ex);
+    }
+    const f4 hy_nx = shift_right(hy_n, lane, e_hy);
+    const f4 hz_nx = shift_right(hz_n, lane, e_hz);
+
+    // sources of this word
+    unsigned srcflag = 0;
+    for (int s = 0; s < a.nsrc; ++s)
+        if (a.src_word[s] == t) srcflag |= 1u << a.src_comp[s];
+
+    // D, fdtd_calculations.cu:97-121 and :205-210
+    f4 dn[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float vx = (d0[0][i] + g.cy * (hz_n[i] - hz_ny[i])) - g.cz * (hy_n[i] - hy_nz[i]);
+        const float vy = (d0[1][i] + g.cz * (hx_n[i] - hx_nz[i])) - g.cx * (hz_n[i] - hz_nx[i]);
+        const float vz = (d0[2][i] + g.cx * (hy_n[i] - hy_nx[i])) - g.cy * (hx_n[i] - hx_ny[i]);
+        dn[0][i] = (x_hi[i] && y_lo && y_hi && z_lo && z_hi) ? vx : d1[0][i];
+        dn[1][i] = (x_lo[i] && x_hi[i] && y_hi && z_lo && z_hi) ? vy : d1[1][i];
+        float dz = (x_lo[i] && x_hi[i] && y_lo && y_hi && z_hi) ? vz : d1[2][i];
+        if ((srcflag >> i) & 1u) dz = vz - a.jz;
+        dn[2][i] = dz;
+    }
+
+    // E, fdtd_calculations.cu:147-182
+    f4 en[3];
+    bool uniform = true;
+    MatEntry mu = a.one;
+    if (!ONE) {
+        const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cd) & 0xffu;
+        uniform = __all(cd == c0 * 0x01010101u);
+        if (uniform) mu = a.table[c0];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        MatEntry m = mu;
+        if (!ONE && !uniform) m = a.table[(cd >> (8 * i)) & 0xffu];
+        const bool g_ex = x_hi[i] && y_lo && y_hi && z_lo && z_hi;
+        const bool g_eyz = x_lo[i] && z_lo;
+        en[0][i] = g_ex ? e_update(m, g.dt, ex_c[i], e1[0][i], dn[0][i], d0[0][i], d1[0][i]) : e1[0][i];
+        en[1][i] = g_eyz ? e_update(m, g.dt, ey_c[i], e1[1][i], dn[1][i], d0[1][i], d1[1][i]) : e1[1][i];
+        en[2][i] = g_eyz ? e_update(m, g.dt, ez_c[i], e1[2][i], dn[2][i], d0[2][i], d1[2][i]) : e1[2][i];
+    }
+
+    if (act) {
+        st4_stream(a.h_w[0] + o, hx_n);
+        st4_stream(a.h_w[1] + o, hy_n);
+        st4_stream(a.h_w[2] + o, hz_n);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            st4_stream(a.d_w[c] + o, dn[c]);
+            st4_stream(a.e_w[c] + o, en[c]);
+        }
+        // the H halo plane below a slab is kept current here, so H is never exchanged
+        if (k == 0 && g.has_lower) {
+            *(f4 *)(a.h_w[0] + o - ps) = hx_nz;
+            *(f4 *)(a.h_w[1] + o - ps) = hy_nz;
+        }
+    }
+}
+
+} // namespace
+
+void launch_sweep3d(const Fused3D &a, void *stream)
+{
+    const long long blocks = (a.total4 + 255) / 256;
+    const dim3 grid((unsigned)((blocks + 511) / 512 * 512));
+    if (a.ntab == 1)
+        hipLaunchKernelGGL(fdtd3d_sweep<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(fdtd3d_sweep<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+}
+
+const char *sweep3d_kernel_name() { return "fdtd3d_sweep"; }
+
+} // namespace fdtd

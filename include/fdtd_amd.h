@@ -52,7 +52,7 @@ enum { FDTD_MODE_AUTO = 0, FDTD_MODE_3D = 1, FDTD_MODE_2D_TMZ = 2 };
  * per step in vacuum), or d = a + b - sigma*dt^2 (bounded). */
 enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
 /* SPLIT: an H kernel and a fused D+source+E kernel (H updated in place).
- * FUSED: one sweep per step (2-D only; H double-buffered). */
+ * FUSED: one sweep over memory per step (H double-buffered); the default. */
 enum { FDTD_KERNEL_AUTO = 0, FDTD_KERNEL_SPLIT = 1, FDTD_KERNEL_FUSED = 2 };
 
 typedef struct fdtd_options {

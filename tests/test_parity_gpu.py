@@ -37,20 +37,23 @@ def test_3d_shipped_case_against_recorded_probe_series(golden):
                 assert f"{float(g):.8e}" == f"{w:.8e}", (step, got)
 
 
-def test_3d_vacuum_fields_match_oracle(oracle):
-    s, o = util.pair(oracle, (100, 100, 100), [(49, 49, 49)], REF)
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, B.KERNEL_SPLIT])
+def test_3d_vacuum_fields_match_oracle(oracle, kernel):
+    s, o = util.pair(oracle, (100, 100, 100), [(49, 49, 49)], REF, kernel=kernel)
     assert util.run_and_compare(s, o, 90, 30, "100^3 vacuum") == 0
 
 
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, B.KERNEL_SPLIT])
 @pytest.mark.parametrize("dims,ecoef", [((23, 19, 17), REF), ((23, 19, 17), CON), ((64, 5, 9), CON),
-                                         ((3, 3, 3), REF), ((130, 7, 4), REF)])
-def test_3d_random_state_debye_and_mur(oracle, dims, ecoef):
+                                         ((3, 3, 3), REF), ((130, 7, 4), REF), ((265, 12, 6), CON),
+                                         ((300, 9, 5), CON)])
+def test_3d_random_state_debye_and_mur(oracle, dims, ecoef, kernel):
     """Random fields, random tissue map, non-uniform rp planes, two sources: every
     term of every kernel (all 12 Mur cases, the ey high-x quirk) is exercised."""
     nx, ny, nz = dims
     rng = np.random.default_rng(1234 + nx)
-    srcs = [(nx // 2, ny // 2, nz // 2), (nx - 1, ny - 1, nz - 1)]
-    s, o = util.pair(oracle, dims, srcs, ecoef, sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    srcs = [(nx // 2, ny // 2, nz // 2), (nx - 1, ny - 1, nz - 1), (1, 1, 0)]
+    s, o = util.pair(oracle, dims, srcs, ecoef, kernel=kernel, sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
     codes = rng.integers(0, len(util.RIKEN_LIKE), size=(nz, ny, nx), dtype=np.uint8)
     util.set_materials(s, o, codes)
     for face in range(6):
@@ -183,15 +186,16 @@ def test_2d_slabs_equal_whole_grid(oracle, kernel, world):
     assert np.abs(whole.field(B.EZ)).max() > 0
 
 
-def test_3d_slabs_equal_whole_grid(oracle):
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, B.KERNEL_SPLIT])
+def test_3d_slabs_equal_whole_grid(oracle, kernel):
     nx, ny, nz = 40, 21, 30
     rng = np.random.default_rng(8)
     srcs = [(20, 10, 15), (5, 5, 9), (5, 5, 10)]
     pa = fdtd_amd.make_params(nx, ny, nz, srcs, sigma=0.1, eps_s=5.0, eps_i=2.0, tau_d=1e-11)
-    whole = fdtd_amd.Solver(pa, ecoef=CON)
+    whole = fdtd_amd.Solver(pa, ecoef=CON, kernel=kernel)
     codes = rng.integers(0, len(util.RIKEN_LIKE), size=(nz, ny, nx), dtype=np.uint8)
     parts = fdtd_amd.partition_rows(nz, 3)
-    slabs = [fdtd_amd.Solver(pa, ecoef=CON, slab=part) for part in parts]
+    slabs = [fdtd_amd.Solver(pa, ecoef=CON, kernel=kernel, slab=part) for part in parts]
     for sv, (b, n) in zip([whole] + slabs, [(0, nz)] + parts):
         for code, row in enumerate(util.RIKEN_LIKE):
             sv.set_material(code, *[float(v) for v in row])
@@ -272,8 +276,6 @@ def test_create_rejects_bad_inputs():
         fdtd_amd.Solver(fdtd_amd.make_params(2, 10, 1, [(1, 1, 0)]))
     with pytest.raises(fdtd_amd.FdtdError, match="source_location"):
         fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 1, [(0, 5, 0)]))
-    with pytest.raises(fdtd_amd.FdtdError, match="fused"):
-        fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 10, [(5, 5, 5)]), kernel=B.KERNEL_FUSED)
     with pytest.raises(fdtd_amd.FdtdError, match="slab"):
         fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 1, [(5, 5, 0)]), slab=(8, 5))
     s = fdtd_amd.Solver(fdtd_amd.make_params(10, 10, 1, [(5, 5, 0)]))

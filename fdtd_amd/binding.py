@@ -81,6 +81,8 @@ SYMBOLS = [
     ("fdtd_set_probes", _I, [_VP, _I, _VP, _I]),
     ("fdtd_probe_fields", _I, [_VP]),
     ("fdtd_read_probes", _I, [_VP, C.c_int64, _I, _VP, _SZ]),
+    ("fdtd_checkpoint_save", _I, [_VP, C.c_char_p]),
+    ("fdtd_checkpoint_load", _I, [_VP, C.c_char_p]),
     ("fdtd_halo_count", _SZ, [_VP]),
     ("fdtd_halo_get", _I, [_VP, _I, _VP, _SZ]),
     ("fdtd_halo_put", _I, [_VP, _I, _VP, _SZ]),
@@ -281,6 +283,12 @@ class Solver:
         out = np.empty((nsteps, self._nprobes, nf), dtype=np.float32)
         _check(self.lib.fdtd_read_probes(self._ctx, first_step, nsteps, out.ctypes.data, out.size))
         return out
+
+    def checkpoint_save(self, path):
+        _check(self.lib.fdtd_checkpoint_save(self._ctx, os.fsencode(path)))
+
+    def checkpoint_load(self, path):
+        _check(self.lib.fdtd_checkpoint_load(self._ctx, os.fsencode(path)))
 
     # -- slabs
     @property

@@ -117,7 +117,7 @@ struct Mur3D {
 };
 
 // The fused 3-D sweep (sweep3d.hip): H read and write generations, sources as
-// word indices into the flat run of 16-byte words of the owned planes.
+// word indices (plane * plane_words + word within the plane).
 struct Fused3D {
     Grid3D g;
     const float *e_n[3];
@@ -132,7 +132,9 @@ struct Fused3D {
     int ntab;
     int nsrc;
     float jz;
-    long long total4;                      // 16-byte words of the owned planes: nzl * ny * pitch / 4
+    long long plane_words;                 // 16-byte words of one plane: ny * pitch / 4
+    int seg_words;                         // words of one XCD's segment of a plane (plane_words / 8, rounded up)
+    int seg_blocks;                        // 256-thread blocks per segment
     long long src_word[FDTD_MAX_SOURCES];  // word holding the source cell, -1 if another slab holds it
     int src_comp[FDTD_MAX_SOURCES];        // which of the word's four cells
 };

@@ -2,11 +2,12 @@
 // updateHField + updateDField + updateSources + updateEField
 // (fdtd_calculations.cu:32-213) fused.
 //
-// Work decomposition.  The owned planes of a field are one flat run of 16-byte
-// words (rows of pitch/4 words, ny rows per plane); thread t owns word t, i.e.
-// four consecutive x cells of one (y, z) row, and a block owns 256 consecutive
-// words -- 4 KB of every array, the access pattern of a flat copy.  Blocks are
-// grouped in bands of 512 and dealt so that each XCD walks 64 consecutive blocks.
+// Work decomposition.  A plane of a field is one flat run of 16-byte words (rows
+// of pitch/4 words, ny rows); a thread owns one word, i.e. four consecutive x
+// cells of one (y, z) row, and a block owns 256 consecutive words -- 4 KB of
+// every array.  Each plane is cut into 8 segments, one per XCD; an XCD walks its
+// segment plane after plane, so what it re-reads of the planes z-1 and z+1 is
+// still in its own L2.
 //
 // Neighbours.  D^{n+1}(c) needs the NEW H at c and at c-x, c-y, c-z.  Those six
 // neighbour values are recomputed here from the old H and E^n of the
@@ -18,6 +19,8 @@
 //
 // Traffic per cell from HBM: 3 H + 3 E^n + 3 E^{n-1} + 3 D^n + 3 D^{n-1} in
 // (60 B) + 1 B material code, 3 H + 3 E^{n+1} + 3 D^{n+1} out (36 B) = 97 B.
+#include <cstdlib>
+
 #include "device_math.h"
 
 namespace fdtd {
@@ -49,22 +52,22 @@ __device__ __forceinline__ f4 shift_right(f4 v, int lane, float edge)
     return r;
 }
 
-template <bool ONE> __global__ __launch_bounds__(256) void fdtd3d_sweep(const Fused3D a)
+template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_sweep(const Fused3D a)
 {
     const Grid3D &g = a.g;
     const int lane = threadIdx.x & 63;
-    // band order: 512 blocks per band, XCD i (block id mod 8) walks blocks [64 i, 64 i + 64) of the band
-    const unsigned bl = blockIdx.x & 511u;
-    const unsigned blk = (blockIdx.x & ~511u) + ((bl & 7u) << 6) + (bl >> 3);
-    const long long t = (long long)blk * 256 + threadIdx.x;
-
+    // Block ids are dealt to the 8 XCDs in turn.  XCD i (block id mod 8) owns segment i --
+    // one eighth of the words -- of EVERY plane and walks the planes in z order, so the
+    // lines of plane z-1 and z+1 it needs are the ones it pulled into its own L2 a plane ago.
     const int p4 = g.pitch >> 2;
-    const long long rowid = t / p4;
-    const int i4 = (int)(t - rowid * p4);
-    const int y = (int)(rowid % g.ny);
-    const int k = (int)(rowid / g.ny);
-    const int x4 = i4 * 4;
-    const bool act = t < a.total4 && x4 < g.nx;
+    const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
+    const int k = (int)(seq / (unsigned)a.seg_blocks);
+    const unsigned in_seg = (seq % (unsigned)a.seg_blocks) * 256u + threadIdx.x;
+    const unsigned in_plane = xcd * (unsigned)a.seg_words + in_seg;      // word within the plane
+    const int y = (int)(in_plane / (unsigned)p4);
+    const int x4 = (int)(in_plane % (unsigned)p4) * 4;
+    const long long t = (long long)k * a.plane_words + in_plane;
+    const bool act = in_seg < (unsigned)a.seg_words && in_plane < (unsigned)a.plane_words && k < g.nzl && x4 < g.nx;
     const int z = g.gz0 + k;
     const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
     const size_t o = act ? (size_t)(k + 1) * ps + (size_t)y * rs + x4 : ps;
@@ -221,12 +224,22 @@ template <bool ONE> __global__ __launch_bounds__(256) void fdtd3d_sweep(const Fu
 
 void launch_sweep3d(const Fused3D &a, void *stream)
 {
-    const long long blocks = (a.total4 + 255) / 256;
-    const dim3 grid((unsigned)((blocks + 511) / 512 * 512));
-    if (a.ntab == 1)
-        hipLaunchKernelGGL(fdtd3d_sweep<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)a.g.nzl);
+    static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 2;
+#define GO(W)                                                                                     \
+    do {                                                                                          \
+        if (a.ntab == 1)                                                                          \
+            hipLaunchKernelGGL((fdtd3d_sweep<true, W>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
+        else                                                                                      \
+            hipLaunchKernelGGL((fdtd3d_sweep<false, W>), grid, dim3(256), 0, (hipStream_t)stream, a); \
+    } while (0)
+    if (waves == 3)
+        GO(3);
+    else if (waves == 4)
+        GO(4);
     else
-        hipLaunchKernelGGL(fdtd3d_sweep<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+        GO(2);
+#undef GO
 }
 
 const char *sweep3d_kernel_name() { return "fdtd3d_sweep"; }

@@ -182,6 +182,15 @@ int fdtd_set_probes(fdtd_ctx *ctx, int count, const int32_t *xyz, int capacity);
 int fdtd_probe_fields(const fdtd_ctx *ctx);
 int fdtd_read_probes(fdtd_ctx *ctx, int64_t first_step, int nsteps, float *dst, size_t count);
 
+/* Checkpoint / restart (the reference has none: it dumps every step as text
+ * and never reads anything back).  fdtd_checkpoint_save() writes the
+ * time-dependent state of the slab -- all field arrays, time level indices and
+ * the step counter -- as one raw binary file; fdtd_checkpoint_load() restores
+ * it into a context created with the same parameters and options.  Materials,
+ * rp planes and probes are inputs, not state: set them up as before. */
+int fdtd_checkpoint_save(fdtd_ctx *ctx, const char *path);
+int fdtd_checkpoint_load(fdtd_ctx *ctx, const char *path);
+
 /* ---- slabs across GPUs ------------------------------------------------ */
 
 /* Halo rows of the slab axis.  side 0 = towards lower indices, 1 = towards

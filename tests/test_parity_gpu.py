@@ -354,3 +354,37 @@ def test_cli_runs_like_the_reference_and_writes_its_output_format(oracle, tmp_pa
     # a missing parameter file is reported and fails the process, it does not crash
     bad = subprocess.run([exe, "--params", "data/none"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "Error" in bad.stdout
+
+
+# ------------------------------------------------------------------ checkpoint / restart
+
+@pytest.mark.parametrize("dims", [(300, 200, 1), (40, 30, 20)])
+def test_checkpoint_restart_continues_bit_exactly(oracle, tmp_path, dims):
+    src = [(dims[0] // 2, dims[1] // 2, dims[2] // 2)]
+    rng = np.random.default_rng(21)
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=dims[::-1], dtype=np.uint8)
+
+    def make():
+        s = fdtd_amd.Solver(fdtd_amd.make_params(*dims, src), ecoef=CON)
+        for code, row in enumerate(util.RIKEN_LIKE):
+            s.set_material(code, *[float(v) for v in row])
+        s.set_codes(codes)
+        return s
+
+    a = make()
+    a.step(37)
+    path = str(tmp_path / "state.ckp")
+    a.checkpoint_save(path)
+    a.step(41)
+    b = make()
+    b.checkpoint_load(path)
+    assert b.steps_done == 37
+    b.step(41)
+    for fid in util.fields_of(a):
+        assert np.array_equal(a.field(fid).view(np.uint32), b.field(fid).view(np.uint32)), B.FIELD_NAMES[fid]
+    assert np.abs(a.field(B.EZ)).max() > 0
+    other = fdtd_amd.Solver(fdtd_amd.make_params(dims[0] + 4, dims[1], dims[2], src), ecoef=CON)
+    with pytest.raises(fdtd_amd.FdtdError, match="another shape"):
+        other.checkpoint_load(path)
+    with pytest.raises(fdtd_amd.FdtdError, match="open"):
+        b.checkpoint_load(str(tmp_path / "missing"))

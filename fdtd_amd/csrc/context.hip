@@ -927,6 +927,8 @@ int fdtd_halo_put(fdtd_ctx *c, int side, const float *src, size_t count)
 // Raw binary image of the time-dependent state: a header, then every field
 // array as it is stored (halo rows and padding included) in a fixed order.
 
+} // extern "C"
+
 namespace {
 
 struct CheckpointHeader {

@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--kernel", choices=["auto", "split", "fused"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--snapshot-every", type=int, default=0,
+                    help="take an ez snapshot (side-stream D2H) every N steps inside the timed region")
     args = ap.parse_args()
 
     import numpy as np
@@ -128,7 +130,19 @@ def main():
     solver.profile_begin(args.steps)
     barrier()
     t0 = time.perf_counter()
-    solver.step(args.steps)
+    snapshots = 0
+    if args.snapshot_every > 0:
+        done = 0
+        while done < args.steps:
+            n = min(args.snapshot_every, args.steps - done)
+            solver.step(n)
+            done += n
+            if done % args.snapshot_every == 0:
+                solver.snapshot_async(B.EZ)            # waits for the previous one, then queues the next
+                snapshots += 1
+        solver.snapshot_wait()
+    else:
+        solver.step(args.steps)
     solver.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -173,6 +187,9 @@ def main():
                 "kernel": solver.sweep_kernel_name,
                 "parallelism": f"slab{world}" if world > 1 else "single",
                 "halo": "RCCL send/recv, 1 ez row per neighbour per step" if world > 1 else "none",
+                "output": (f"{snapshots} ez snapshots per rank (async D2H on a side stream) + 1 probe x "
+                           f"{solver.lib.fdtd_probe_fields(solver._ctx)} fields every step") if snapshots
+                else "1 probe every step",
             },
             "roofline": {
                 "bound": "hbm",

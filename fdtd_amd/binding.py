@@ -78,6 +78,7 @@ SYMBOLS = [
     ("fdtd_write_field", _I, [_VP, _I, _I, _VP, _SZ]),
     ("fdtd_snapshot_async", _I, [_VP, _I, _VP, _SZ]),
     ("fdtd_snapshot_wait", _I, [_VP]),
+    ("fdtd_snapshot_data", C.POINTER(C.c_float), [_VP]),
     ("fdtd_set_probes", _I, [_VP, _I, _VP, _I]),
     ("fdtd_probe_fields", _I, [_VP]),
     ("fdtd_read_probes", _I, [_VP, C.c_int64, _I, _VP, _SZ]),
@@ -266,12 +267,20 @@ class Solver:
             raise FdtdError("set_field: wrong size")
         _check(self.lib.fdtd_write_field(self._ctx, fid, level, data.ctypes.data, data.size))
 
-    def snapshot_async(self, fid, out):
-        assert out.dtype == np.float32 and out.flags.c_contiguous
-        _check(self.lib.fdtd_snapshot_async(self._ctx, fid, out.ctypes.data, out.size))
+    def snapshot_async(self, fid, out=None):
+        """Queue a snapshot; out=None keeps it in the library's pinned buffer (see snapshot_wait)."""
+        if out is None:
+            _check(self.lib.fdtd_snapshot_async(self._ctx, fid, None, int(np.prod(self.shape))))
+        else:
+            assert out.dtype == np.float32 and out.flags.c_contiguous
+            _check(self.lib.fdtd_snapshot_async(self._ctx, fid, out.ctypes.data, out.size))
 
     def snapshot_wait(self):
+        """Block until the queued snapshot is on the host; returns a view of the pinned
+        staging buffer (valid until the next snapshot_async)."""
         _check(self.lib.fdtd_snapshot_wait(self._ctx))
+        ptr = self.lib.fdtd_snapshot_data(self._ctx)
+        return np.ctypeslib.as_array(ptr, shape=self.shape) if ptr else None
 
     def set_probes(self, xyz, capacity):
         xyz = np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1, 3)

@@ -807,10 +807,12 @@ int fdtd_snapshot_wait(fdtd_ctx *c)
     if (!c->snap_pending) return 0;
     if (use_device(c)) return -10;
     HIPCHK(hipStreamSynchronize(c->side));
-    std::memcpy(c->snap_dst, c->snap_host, c->snap_count * sizeof(float));
+    if (c->snap_dst) std::memcpy(c->snap_dst, c->snap_host, c->snap_count * sizeof(float));
     c->snap_pending = false;
     return 0;
 }
+
+const float *fdtd_snapshot_data(fdtd_ctx *c) { return c->snap_pending ? nullptr : c->snap_host; }
 
 int fdtd_snapshot_async(fdtd_ctx *c, int field, float *dst, size_t count)
 {

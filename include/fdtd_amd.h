@@ -172,6 +172,10 @@ int fdtd_write_field(fdtd_ctx *ctx, int field, int level, const float *src, size
  * blocks until the data is in dst. */
 int fdtd_snapshot_async(fdtd_ctx *ctx, int field, float *dst, size_t count);
 int fdtd_snapshot_wait(fdtd_ctx *ctx);
+/* With dst = NULL the snapshot stays in the library's pinned staging buffer:
+ * after fdtd_snapshot_wait() this returns it (count floats, valid until the
+ * next fdtd_snapshot_async) and saves the copy into caller memory. */
+const float *fdtd_snapshot_data(fdtd_ctx *ctx);
 
 /* Probe time series: up to FDTD_MAX_PROBES cells (global 0-based x, y, z);
  * after every step the values of hx, hy, dz, ez (2-D) or all nine fields (3-D)

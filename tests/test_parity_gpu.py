@@ -265,10 +265,14 @@ def test_probes_and_snapshot_agree_with_read_field(oracle):
         series.append([[o.field(f)[0, y, x] for f in (B.HX, B.HY, B.DZ, B.EZ)] for x, y, _ in probes])
     s.snapshot_wait()
     assert np.array_equal(snap.view(np.uint32), want_snap.view(np.uint32))
+    s.snapshot_async(B.HY)                      # zero-copy form: the pinned staging buffer
+    hy_now = s.field(B.HY)
+    s.step(3)
+    assert np.array_equal(s.snapshot_wait().view(np.uint32), hy_now.view(np.uint32))
     got = s.read_probes(0, 50)
     assert np.array_equal(got.view(np.uint32), np.array(series, dtype=np.float32).view(np.uint32))
     with pytest.raises(fdtd_amd.FdtdError):
-        s.read_probes(0, 51)
+        s.read_probes(0, 54)      # 53 steps were taken
 
 
 def test_create_rejects_bad_inputs():

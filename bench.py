@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--kernel", choices=["auto", "split", "fused"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--device", type=int, default=-1, help="GPU ordinal (default: LOCAL_RANK)")
     ap.add_argument("--snapshot-every", type=int, default=0,
                     help="take an ez snapshot (side-stream D2H) every N steps inside the timed region")
     args = ap.parse_args()
@@ -86,6 +87,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.device >= 0:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
 
     dist = None
@@ -113,10 +116,34 @@ def main():
     kernel = {"auto": B.KERNEL_AUTO, "split": B.KERNEL_SPLIT, "fused": B.KERNEL_FUSED}[args.kernel]
     solver = fdtd_amd.Solver(params, ecoef=B.ECOEF_CONSISTENT, kernel=kernel, device=local_rank,
                              slab=slab if world > 1 else None, chunk_rows=args.chunk_rows)
+    halo = "none"
+    stepper = solver
     if world > 1:
-        ids = [fdtd_amd.binding.comm_unique_id() if rank == 0 else None]
+        # Halo exchange inside the library over RCCL.  Should RCCL not come up on this node,
+        # every rank falls back to the host-staged exchange (same kernels, halo rows moved by
+        # gloo) and the JSON line says so -- a slower run is more useful than no run.
+        err = ""
+        try:
+            ids = [fdtd_amd.binding.comm_unique_id() if rank == 0 else None]
+        except fdtd_amd.FdtdError as e:
+            ids, err = [None], str(e)
         dist.broadcast_object_list(ids, src=0)
-        solver.comm_init(ids[0], rank, world)
+        if ids[0] is not None:
+            try:
+                solver.comm_init(ids[0], rank, world)
+                solver.comm_selftest()
+            except fdtd_amd.FdtdError as e:
+                err = str(e)
+        flags = [None] * world
+        dist.all_gather_object(flags, err)
+        if any(flags):
+            if rank == 0:
+                print(f"bench.py: RCCL unavailable ({[f for f in flags if f][0]}); host-staged halo exchange",
+                      file=sys.stderr)
+            stepper = fdtd_amd.SlabRunner(solver, rank, world, transport="host")
+            halo = "host-staged over gloo (RCCL failed to initialise), 1 E row per neighbour per step"
+        else:
+            halo = "RCCL send/recv, 1 E row per neighbour per step"
 
     src_rank = min(world - 1, src[0][2 if is3d else 1] // (args.nz if is3d else args.ny))
     solver.set_probes([src[0]], capacity=args.steps + args.warmup)
@@ -126,7 +153,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    solver.step(args.warmup)
+    stepper.step(args.warmup)
     solver.profile_begin(args.steps)
     barrier()
     t0 = time.perf_counter()
@@ -135,14 +162,14 @@ def main():
         done = 0
         while done < args.steps:
             n = min(args.snapshot_every, args.steps - done)
-            solver.step(n)
+            stepper.step(n)
             done += n
             if done % args.snapshot_every == 0:
                 solver.snapshot_async(B.EZ)            # waits for the previous one, then queues the next
                 snapshots += 1
         solver.snapshot_wait()
     else:
-        solver.step(args.steps)
+        stepper.step(args.steps)
     solver.sync()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -186,7 +213,7 @@ def main():
                 "ecoef": "consistent",
                 "kernel": solver.sweep_kernel_name,
                 "parallelism": f"slab{world}" if world > 1 else "single",
-                "halo": "RCCL send/recv, 1 ez row per neighbour per step" if world > 1 else "none",
+                "halo": halo,
                 "output": (f"{snapshots} ez snapshots per rank (async D2H on a side stream) + 1 probe x "
                            f"{solver.lib.fdtd_probe_fields(solver._ctx)} fields every step") if snapshots
                 else "1 probe every step",

@@ -58,6 +58,21 @@ def measured_traffic(workload):
         return None
 
 
+class stdout_to_stderr:
+    """Libraries (gloo, RCCL) print banners on fd 1 while they initialise; stdout is reserved
+    for the one JSON line, so fd 1 points at stderr inside this block."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,7 +111,8 @@ def main():
         import torch.distributed as dist
         # control plane (rendezvous, barrier, max over ranks) on gloo; the data plane
         # is the library's own RCCL communicator (ncclSend/ncclRecv of halo rows)
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        with stdout_to_stderr():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     is3d = args.nz > 1
     nx = args.nx
@@ -130,8 +146,9 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         if ids[0] is not None:
             try:
-                solver.comm_init(ids[0], rank, world)
-                solver.comm_selftest()
+                with stdout_to_stderr():
+                    solver.comm_init(ids[0], rank, world)
+                    solver.comm_selftest()
             except fdtd_amd.FdtdError as e:
                 err = str(e)
         flags = [None] * world

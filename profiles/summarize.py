@@ -8,10 +8,17 @@ from collections import defaultdict
 src = sys.argv[1]
 kernel = sys.argv[2] if len(sys.argv) > 2 else "fdtd2d_sweep"
 out = {"kernel": kernel, "source": src}
-for path in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: keep the latest run only."""
+    paths = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return paths[-1:]
+
+
+for path in newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     out["kernel_stats"] = [dict(r) for r in csv.DictReader(open(path))]
 counters = defaultdict(list)
-for path in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+for group in glob.glob(os.path.join(src, "pmc_*")):
+  for path in newest(os.path.join(group, "*", "*_counter_collection.csv")):
     for r in csv.DictReader(open(path)):
         if kernel in r["Kernel_Name"]:
             counters[r["Counter_Name"]].append(float(r["Counter_Value"]))

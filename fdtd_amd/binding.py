@@ -76,6 +76,7 @@ SYMBOLS = [
     ("fdtd_sweep_kernel_name", C.c_char_p, [_VP]),
     ("fdtd_read_field", _I, [_VP, _I, _I, _VP, _SZ]),
     ("fdtd_write_field", _I, [_VP, _I, _I, _VP, _SZ]),
+    ("fdtd_read_window", _I, [_VP, _I, _I, C.c_int64, C.c_int64, _I, _I, _VP]),
     ("fdtd_snapshot_async", _I, [_VP, _I, _VP, _SZ]),
     ("fdtd_snapshot_wait", _I, [_VP]),
     ("fdtd_snapshot_data", C.POINTER(C.c_float), [_VP]),
@@ -259,6 +260,12 @@ class Solver:
     def field(self, fid, level=0):
         out = np.empty(self.shape, dtype=np.float32)
         _check(self.lib.fdtd_read_field(self._ctx, fid, level, out.ctypes.data, out.size))
+        return out
+
+    def window(self, fid, first_row, nrows, x0, ncols, level=0):
+        """Rows first_row.. of the slab (3-D: row = z * ny + y), columns x0..: an [nrows][ncols] array."""
+        out = np.empty((nrows, ncols), dtype=np.float32)
+        _check(self.lib.fdtd_read_window(self._ctx, fid, level, first_row, nrows, x0, ncols, out.ctypes.data))
         return out
 
     def set_field(self, fid, data, level=0):

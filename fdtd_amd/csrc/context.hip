@@ -786,6 +786,23 @@ int fdtd_read_field(fdtd_ctx *c, int field, int level, float *dst, size_t count)
     return 0;
 }
 
+int fdtd_read_window(fdtd_ctx *c, int field, int level, int64_t first_row, int64_t nrows, int x0, int ncols,
+                     float *dst)
+{
+    if (use_device(c)) return -10;
+    FieldView v;
+    int rc = field_view(c, field, level, &v);
+    if (rc) return rc;
+    if (first_row < 0 || nrows < 1 || first_row + nrows > (int64_t)v.rows || x0 < 0 || ncols < 1 || x0 + ncols > c->nx) {
+        set_error("fdtd_read_window: the window must lie inside the slab");
+        return -3;
+    }
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)ncols * 4, v.ptr + (size_t)first_row * c->pitch + x0, (size_t)c->pitch * 4,
+                            (size_t)ncols * 4, (size_t)nrows, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
 int fdtd_write_field(fdtd_ctx *c, int field, int level, const float *src, size_t count)
 {
     if (use_device(c)) return -10;

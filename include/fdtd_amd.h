@@ -165,6 +165,12 @@ const char *fdtd_sweep_kernel_name(const fdtd_ctx *ctx);
  * deliver.  level 0 = newest, 1 = previous time level (E and D only). */
 int fdtd_read_field(fdtd_ctx *ctx, int field, int level, float *dst, size_t count);
 int fdtd_write_field(fdtd_ctx *ctx, int field, int level, const float *src, size_t count);
+/* A rectangle of the same data: rows first_row .. first_row + nrows - 1 of the
+ * slab (2-D: local y; 3-D: local z * ny + y, so one z slice -- the unit the
+ * writers of fdtd.cu:1288-1494 put into one file -- is ny consecutive rows),
+ * columns x0 .. x0 + ncols - 1, packed into dst[nrows][ncols]. */
+int fdtd_read_window(fdtd_ctx *ctx, int field, int level, int64_t first_row, int64_t nrows, int x0, int ncols,
+                     float *dst);
 
 /* Snapshot of one field on a side stream: a device-to-device copy ordered
  * after the steps queued so far, then an async D2H into pinned staging; the

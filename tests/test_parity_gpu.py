@@ -315,6 +315,34 @@ def test_2d_full_size_16384_window_and_causality(oracle):
         del full
 
 
+@pytest.mark.timeout(900)
+def test_2d_largest_grid_65536_window_and_causality(oracle):
+    """65536 x 65536 (4.3 G cells, 142 GB resident: byte offsets need 36 bits), source off
+    centre in the upper half so every index of the window lies beyond 2^32 bytes.  Same
+    translation-invariance and causality checks as at 16384^2, read through windows."""
+    import torch
+    free, _ = torch.cuda.mem_get_info()
+    if free < 160e9:
+        pytest.skip("needs 160 GB of free HBM")
+    n, steps, w = 65536, 60, 256
+    sx, sy = 40000, 50000
+    s = fdtd_amd.Solver(fdtd_amd.make_params(n, n, 1, [(sx, sy, 0)]), ecoef=CON)
+    s.set_probes([(sx, sy, 0)], capacity=steps)
+    o = oracle.Oracle(oracle.make_params(w, w, 1, [(w // 2, w // 2, 0)]), ecoef=CON)
+    s.step(steps)
+    o.step(steps, threads=8)
+    for fid in (B.HX, B.HY, B.DZ, B.EZ):
+        win = s.window(fid, sy - w // 2, w, sx - w // 2, w)
+        assert np.array_equal(win.view(np.uint32), np.asarray(o.field(fid)[0]).view(np.uint32)), B.FIELD_NAMES[fid]
+        assert np.any(win != 0)
+        # nothing outside the light cone: a frame of windows around it, and the far corners
+        for row0, x0 in ((sy - 2 * w, sx - w // 2), (sy + w, sx - w // 2), (sy - w // 2, sx - 2 * w),
+                         (sy - w // 2, sx + w), (0, 0), (n - w, n - w), (0, n - w), (n - w, 0)):
+            assert not np.any(s.window(fid, row0, w, x0, w)), (B.FIELD_NAMES[fid], row0, x0)
+    assert np.all(np.isfinite(s.read_probes(0, steps)))
+    s.close()
+
+
 # ------------------------------------------------------------------ command-line driver
 
 def test_cli_runs_like_the_reference_and_writes_its_output_format(oracle, tmp_path):

@@ -82,7 +82,8 @@ def main():
     ap.add_argument("--ny", type=int, default=16384, help="rows per GPU")
     ap.add_argument("--nz", type=int, default=1, help="> 1 selects the 3-D path (z planes per GPU)")
     ap.add_argument("--chunk-rows", type=int, default=0)
-    ap.add_argument("--kernel", choices=["auto", "split", "fused"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "split", "fused", "multistep"], default="auto")
+    ap.add_argument("--steps-per-pass", type=int, default=0, help="multistep kernel: time steps per pass (2..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device", type=int, default=-1, help="GPU ordinal (default: LOCAL_RANK)")
     ap.add_argument("--snapshot-every", type=int, default=0,
@@ -129,9 +130,12 @@ def main():
         cells_per_rank = nx * args.ny
         bytes_per_cell = BYTES_PER_CELL_2D
     params = fdtd_amd.make_params(*gdims, src)
-    kernel = {"auto": B.KERNEL_AUTO, "split": B.KERNEL_SPLIT, "fused": B.KERNEL_FUSED}[args.kernel]
+    kernel = {"auto": B.KERNEL_AUTO, "split": B.KERNEL_SPLIT, "fused": B.KERNEL_FUSED,
+              "multistep": B.KERNEL_MULTISTEP}[args.kernel]
     solver = fdtd_amd.Solver(params, ecoef=B.ECOEF_CONSISTENT, kernel=kernel, device=local_rank,
-                             slab=slab if world > 1 else None, chunk_rows=args.chunk_rows)
+                             slab=slab if world > 1 else None, chunk_rows=args.chunk_rows,
+                             steps_per_pass=args.steps_per_pass)
+    spp = solver.steps_per_pass          # time steps one launch of the sweep advances
     halo = "none"
     stepper = solver
     if world > 1:
@@ -208,7 +212,7 @@ def main():
         total_cells = cells_per_rank * world
         value = total_cells * args.steps / elapsed / 1e6
         sweep_avg_ms = float(np.mean(sweep_ms)) if len(sweep_ms) else float("nan")
-        achieved = cells_per_rank * bytes_per_cell / (sweep_avg_ms * 1e-3) / 1e9
+        achieved = cells_per_rank * spp * bytes_per_cell / (sweep_avg_ms * 1e-3) / 1e9
         workload = (f"{gdims[0]}x{gdims[1]}x{gdims[2]} 3-D" if is3d else f"{gdims[0]}x{gdims[1]} 2-D TMz") + \
             " vacuum + centre point source"
         out = {
@@ -229,6 +233,7 @@ def main():
                 "cells_per_gpu": cells_per_rank,
                 "ecoef": "consistent",
                 "kernel": solver.sweep_kernel_name,
+                "steps_per_pass": spp,
                 "parallelism": f"slab{world}" if world > 1 else "single",
                 "halo": halo,
                 "output": (f"{snapshots} ez snapshots per rank (async D2H on a side stream) + 1 probe x "
@@ -245,6 +250,7 @@ def main():
                 "kernel": solver.sweep_kernel_name,
                 "kernel_avg_ms": sweep_avg_ms,
                 "algorithmic_bytes_per_cell": bytes_per_cell,
+                "cell_updates_per_launch": cells_per_rank * spp,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

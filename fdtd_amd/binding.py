@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_SOURCES, MAX_JZ, MAX_CODES, MAX_PROBES = 16, 512, 256, 16
 MODE_AUTO, MODE_3D, MODE_2D_TMZ = 0, 1, 2
 ECOEF_REFERENCE, ECOEF_CONSISTENT = 0, 1
-KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED = 0, 1, 2
+KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MULTISTEP = 0, 1, 2, 3
 HX, HY, HZ, DX, DY, DZ, EX, EY, EZ = range(9)
 FIELD_NAMES = ["hx", "hy", "hz", "dx", "dy", "dz", "ex", "ey", "ez"]
 DEFAULT_CODE = 255
@@ -43,7 +43,7 @@ class Options(C.Structure):
     _fields_ = [
         ("mode", C.c_int32), ("ecoef", C.c_int32), ("device", C.c_int32), ("kernel", C.c_int32),
         ("slab_begin", C.c_int32), ("slab_count", C.c_int32), ("chunk_rows", C.c_int32),
-        ("reserved", C.c_int32 * 9),
+        ("steps_per_pass", C.c_int32), ("reserved", C.c_int32 * 8),
     ]
 
 
@@ -71,6 +71,7 @@ SYMBOLS = [
     ("fdtd_step", _I, [_VP, _I]),
     ("fdtd_sync", _I, [_VP]),
     ("fdtd_steps_done", C.c_int64, [_VP]),
+    ("fdtd_steps_per_pass", _I, [_VP]),
     ("fdtd_profile_begin", _I, [_VP, _I]),
     ("fdtd_profile_read", _I, [_VP, _VP, _I, C.POINTER(_I)]),
     ("fdtd_sweep_kernel_name", C.c_char_p, [_VP]),
@@ -183,12 +184,15 @@ class Solver:
     """One fdtd_ctx: a whole grid or one slab of it on one GPU."""
 
     def __init__(self, params, mode=MODE_AUTO, ecoef=ECOEF_REFERENCE, kernel=KERNEL_AUTO, device=0,
-                 slab=None, chunk_rows=0):
+                 slab=None, chunk_rows=0, steps_per_pass=0):
         self.lib = load_library()
         self.p = params
         opt = Options()
         self.lib.fdtd_options_default(C.byref(opt))
+        if isinstance(kernel, tuple):            # (KERNEL_MULTISTEP, steps per pass)
+            kernel, steps_per_pass = kernel
         opt.mode, opt.ecoef, opt.kernel, opt.device, opt.chunk_rows = mode, ecoef, kernel, device, chunk_rows
+        opt.steps_per_pass = steps_per_pass
         if slab is not None:
             opt.slab_begin, opt.slab_count = slab
         self._ctx = _VP()
@@ -251,6 +255,10 @@ class Solver:
         n = _I(0)
         _check(self.lib.fdtd_profile_read(self._ctx, ms.ctypes.data, capacity, C.byref(n)))
         return ms[:n.value]
+
+    @property
+    def steps_per_pass(self):
+        return self.lib.fdtd_steps_per_pass(self._ctx)
 
     @property
     def sweep_kernel_name(self):

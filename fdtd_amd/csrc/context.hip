@@ -55,16 +55,21 @@ struct fdtd_ctx {
 
     std::vector<void *> allocs;
     float *h[3][2] = {};
-    float *e[3][2] = {};
-    float *d[3][2] = {};
+    float *e[3][4] = {}; // [component][2 * pair + level slot]; the second pair exists in MULTISTEP mode only
+    float *d[3][4] = {};
     uint8_t *code = nullptr;
     MatEntry *table = nullptr;
     MatEntry table0 = {};
     float *rp[6] = {};
     size_t rp_n[6] = {};
 
-    int cur = 0;  // index of the newest E/D level
+    int cur = 0;  // slot of the newest E/D level inside the current pair
+    int pair = 0; // which pair of E/D arrays holds the two live levels
     int hgen = 0; // index of the newest H generation
+    int tb_steps = 1;  // MULTISTEP: time steps per pass (also the halo depth in rows)
+    int tb_rows = 32;  // MULTISTEP: owned rows per wave
+    int halo = 1;      // halo rows (2-D) on either side of the slab
+    size_t lead = 0;   // floats between the start of an array and local row -1: (halo - 1) * pitch
     int64_t step = 0;
 
     MaterialRow mats[FDTD_MAX_CODES];
@@ -94,6 +99,10 @@ struct fdtd_ctx {
     int rank = 0, world = 1;
 
     bool is2d() const { return mode == FDTD_MODE_2D_TMZ; }
+    bool one_pass() const { return kernel == FDTD_KERNEL_FUSED || kernel == FDTD_KERNEL_MULTISTEP; }
+    // level 0 = newest, 1 = previous
+    float *E(int k, int level) const { return e[k][2 * pair + (level ? cur ^ 1 : cur)]; }
+    float *D(int k, int level) const { return d[k][2 * pair + (level ? cur ^ 1 : cur)]; }
     size_t slab_cells() const { return is2d() ? (size_t)nx * sn : (size_t)nx * ny * sn; }
     int field_comp(int field) const { return field % 3; }
 };
@@ -115,7 +124,7 @@ int alloc_field(fdtd_ctx *c, float **out)
     float *base = nullptr;
     int rc = dev_alloc(c, &base, c->elems + 2 * kSlack);
     if (rc) return rc;
-    *out = base + kSlack;
+    *out = base + kSlack + c->lead;
     return 0;
 }
 
@@ -159,11 +168,16 @@ Grid3D grid3d(const fdtd_ctx *c)
 }
 
 // Sources in global coordinates; the sample index of step n is n - n % 3.
+float jz_of_step(const fdtd_ctx *c, int64_t step)
+{
+    const int64_t i = step - step % 3;
+    return (i >= 0 && i < FDTD_MAX_JZ) ? c->p.jz[i] : 0.0f;
+}
+
 SourceList sources_for_step(const fdtd_ctx *c)
 {
     SourceList s = c->src;
-    const int64_t i = c->step - c->step % 3;
-    s.jz = (i >= 0 && i < FDTD_MAX_JZ) ? c->p.jz[i] : 0.0f;
+    s.jz = jz_of_step(c, c->step);
     return s;
 }
 
@@ -210,9 +224,9 @@ int field_view(fdtd_ctx *c, int field, int level, FieldView *v)
     if (field <= FDTD_HZ)
         base = c->h[k][c->hgen];
     else if (field <= FDTD_DZ)
-        base = c->d[k][level ? c->cur ^ 1 : c->cur];
+        base = c->D(k, level);
     else
-        base = c->e[k][level ? c->cur ^ 1 : c->cur];
+        base = c->E(k, level);
     if (!base) {
         set_error("field is not part of the 2-D TMz mode (hx, hy, dz, ez only)");
         return -3;
@@ -254,7 +268,7 @@ int use_device(const fdtd_ctx *c)
 // ex, ey, ez.  Addresses are in the newest E level.
 float *halo_rows(fdtd_ctx *c, int comp, int side, bool halo)
 {
-    float *base = c->e[comp][c->cur];
+    float *base = c->E(comp, 0);
     const size_t unit = c->is2d() ? (size_t)c->pitch : (size_t)c->ny * c->pitch;
     size_t row;
     if (side == 0)
@@ -263,6 +277,8 @@ float *halo_rows(fdtd_ctx *c, int comp, int side, bool halo)
         row = halo ? (size_t)c->sn + 1 : (size_t)c->sn;
     return base + row * unit;
 }
+
+void record_probes(fdtd_ctx *c, int mid);
 
 int exchange_halos_rccl(fdtd_ctx *c)
 {
@@ -288,14 +304,13 @@ int exchange_halos_rccl(fdtd_ctx *c)
 int step_once(fdtd_ctx *c)
 {
     const bool prof = c->prof_n < c->prof_cap;
-    const int n = c->cur, w = c->cur ^ 1;
     if (c->is2d()) {
         Sweep2D a;
         a.g = grid2d(c);
-        a.ez_n = c->e[2][n];
-        a.ez_w = c->e[2][w];
-        a.dz_n = c->d[2][n];
-        a.dz_w = c->d[2][w];
+        a.ez_n = c->E(2, 0);
+        a.ez_w = c->E(2, 1);
+        a.dz_n = c->D(2, 0);
+        a.dz_w = c->D(2, 1);
         a.code = c->code;
         a.table = c->table;
         a.ntab = c->ntab;
@@ -306,7 +321,7 @@ int step_once(fdtd_ctx *c)
         a.nopad = c->nopad;
         a.src = sources_for_step(c);
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-        if (c->kernel == FDTD_KERNEL_FUSED) {
+        if (c->one_pass()) {
             a.hx_r = c->h[0][c->hgen];
             a.hy_r = c->h[1][c->hgen];
             a.hx_w = c->h[0][c->hgen ^ 1];
@@ -322,8 +337,8 @@ int step_once(fdtd_ctx *c)
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
         Mur2D m;
         m.g = a.g;
-        m.ez_t = c->e[2][w];
-        m.ez_s = c->e[2][n];
+        m.ez_t = c->E(2, 1);
+        m.ez_s = c->E(2, 0);
         m.rpx0 = c->rp[FDTD_RP_X0];
         m.rpxe = c->rp[FDTD_RP_XEND];
         m.rpy0 = c->rp[FDTD_RP_Y0];
@@ -338,10 +353,10 @@ int step_once(fdtd_ctx *c)
         Sweep3D a;
         a.g = grid3d(c);
         for (int k = 0; k < 3; ++k) {
-            a.e_n[k] = c->e[k][n];
-            a.e_w[k] = c->e[k][w];
-            a.d_n[k] = c->d[k][n];
-            a.d_w[k] = c->d[k][w];
+            a.e_n[k] = c->E(k, 0);
+            a.e_w[k] = c->E(k, 1);
+            a.d_n[k] = c->D(k, 0);
+            a.d_w[k] = c->D(k, 1);
             a.h[k] = c->h[k][c->hgen];
         }
         a.code = c->code;
@@ -386,8 +401,8 @@ int step_once(fdtd_ctx *c)
         Mur3D m;
         m.g = a.g;
         for (int k = 0; k < 3; ++k) {
-            m.e_t[k] = c->e[k][w];
-            m.e_s[k] = c->e[k][n];
+            m.e_t[k] = c->E(k, 1);
+            m.e_s[k] = c->E(k, 0);
         }
         for (int f = 0; f < 6; ++f) m.rp[f] = c->rp[f];
         m.dt = c->p.dt;
@@ -405,7 +420,14 @@ int step_once(fdtd_ctx *c)
 
     int rc = exchange_halos_rccl(c);
     if (rc) return rc;
+    record_probes(c, 0);
+    return 0;
+}
 
+// Appends the newest step to the probe ring.  `mid` > 0: the `mid` steps before it were written
+// by the multi-step sweep for the probes this slab holds; the others get their zeros here.
+void record_probes(fdtd_ctx *c, int mid)
+{
     if (c->probes.count > 0 && c->probe_ring) {
         const int slot = (int)((c->step - 1) % c->probe_cap);
         if (c->is2d()) {
@@ -413,19 +435,21 @@ int step_once(fdtd_ctx *c)
             q.g = grid2d(c);
             q.hx = c->h[0][c->hgen];
             q.hy = c->h[1][c->hgen];
-            q.dz = c->d[2][c->cur];
-            q.ez = c->e[2][c->cur];
+            q.dz = c->D(2, 0);
+            q.ez = c->E(2, 0);
             q.p = c->probes;
             q.ring = c->probe_ring;
             q.slot = slot;
+            q.nmid = mid;
+            for (int i = 0; i < mid; ++i) q.mid_slot[i] = (int)((c->step - 2 - i) % c->probe_cap);
             launch_probe2d(q, c->stream);
         } else {
             Probe3D q;
             q.g = grid3d(c);
             for (int k = 0; k < 3; ++k) {
                 q.f[FDTD_HX + k] = c->h[k][c->hgen];
-                q.f[FDTD_DX + k] = c->d[k][c->cur];
-                q.f[FDTD_EX + k] = c->e[k][c->cur];
+                q.f[FDTD_DX + k] = c->D(k, 0);
+                q.f[FDTD_EX + k] = c->E(k, 0);
             }
             q.p = c->probes;
             q.ring = c->probe_ring;
@@ -434,6 +458,77 @@ int step_once(fdtd_ctx *c)
         }
         if (c->step - c->probe_first > c->probe_cap) c->probe_first = c->step - c->probe_cap;
     }
+}
+
+// MULTISTEP: tb_steps time steps in one pass (sweep2d_tb.hip), then Mur on the newest level.
+int pass_once(fdtd_ctx *c)
+{
+    const bool prof = c->prof_n < c->prof_cap;
+    const int K = c->tb_steps;
+    SweepTB a;
+    a.g = grid2d(c);
+    a.hx_r = c->h[0][c->hgen];
+    a.hy_r = c->h[1][c->hgen];
+    a.hx_w = c->h[0][c->hgen ^ 1];
+    a.hy_w = c->h[1][c->hgen ^ 1];
+    a.ez_n = c->E(2, 0);
+    a.ez_p = c->E(2, 1);
+    a.dz_n = c->D(2, 0);
+    a.dz_p = c->D(2, 1);
+    const int other = 2 * (c->pair ^ 1);
+    a.ez_a = c->e[2][other];
+    a.ez_b = c->e[2][other + 1];
+    a.dz_a = c->d[2][other];
+    a.dz_b = c->d[2][other + 1];
+    a.code = c->code;
+    a.table = c->table;
+    a.one = c->table0;
+    a.ntab = c->ntab;
+    a.src = c->src;
+    a.src.jz = 0.0f;
+    for (int s = 0; s < kMaxStepsPerPass; ++s) a.jz[s] = s < K ? jz_of_step(c, c->step + s) : 0.0f;
+    a.rpx0 = c->rp[FDTD_RP_X0];
+    a.rpxe = c->rp[FDTD_RP_XEND];
+    a.rpy0 = c->rp[FDTD_RP_Y0];
+    a.rpye = c->rp[FDTD_RP_YEND];
+    a.dx = c->p.dx;
+    a.dy = c->p.dy;
+    a.mu0 = c->p.mu0;
+    a.eps0 = c->p.eps0;
+    a.probes = c->probes;
+    a.ring = (c->probes.count > 0) ? c->probe_ring : nullptr;
+    for (int s = 0; s < kMaxStepsPerPass; ++s)
+        a.slot[s] = (a.ring && s >= 1 && s < K) ? (int)((c->step + s - 1) % c->probe_cap) : 0;
+    a.rows = c->tb_rows;
+    a.strips = ((c->nx + 3) / 4 + 61) / 62;
+    if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
+    launch_sweep2d_tb(a, K, c->stream);
+    if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
+    c->pair ^= 1;
+    c->cur = 1;
+    c->hgen ^= 1;
+    c->step += K;
+
+    Mur2D m;
+    m.g = a.g;
+    m.ez_t = c->E(2, 0);
+    m.ez_s = c->E(2, 1);
+    m.rpx0 = a.rpx0;
+    m.rpxe = a.rpxe;
+    m.rpy0 = a.rpy0;
+    m.rpye = a.rpye;
+    m.dt = c->p.dt;
+    m.dx = c->p.dx;
+    m.dy = c->p.dy;
+    m.mu0 = c->p.mu0;
+    m.eps0 = c->p.eps0;
+    launch_mur2d(m, c->stream);
+    HIPCHK(hipGetLastError());
+    if (prof) c->prof_n++;
+
+    int rc = exchange_halos_rccl(c);
+    if (rc) return rc;
+    record_probes(c, K - 1);
     return 0;
 }
 
@@ -492,9 +587,22 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     }
     c->ecoef = opt->ecoef;
     c->kernel = opt->kernel == FDTD_KERNEL_AUTO ? FDTD_KERNEL_FUSED : opt->kernel;
-    if (c->kernel != FDTD_KERNEL_SPLIT && c->kernel != FDTD_KERNEL_FUSED) {
+    if (c->kernel != FDTD_KERNEL_SPLIT && c->kernel != FDTD_KERNEL_FUSED && c->kernel != FDTD_KERNEL_MULTISTEP) {
         set_error("unknown kernel selection");
         return -3;
+    }
+    if (c->kernel == FDTD_KERNEL_MULTISTEP) {
+        if (!c->is2d()) {
+            set_error("FDTD_KERNEL_MULTISTEP exists for the 2-D TMz mode only");
+            return -3;
+        }
+        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : 2;
+        if (c->tb_steps < 2 || c->tb_steps > kMaxStepsPerPass) {
+            set_error("steps_per_pass must be 2, 3 or 4");
+            return -3;
+        }
+        if (const char *v = std::getenv("FDTD_TB_ROWS")) c->tb_rows = std::max(2, std::atoi(v));
+        c->halo = c->tb_steps;
     }
     c->gn = c->is2d() ? p->ny : p->nz;
     c->s0 = opt->slab_count > 0 ? opt->slab_begin : 0;
@@ -538,11 +646,13 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     // grid (nx = 265) wastes 3 % of the lanes instead of 17 %.
     const int quantum = (!c->is2d() && c->kernel == FDTD_KERNEL_FUSED) ? 16 : 64;
     c->pitch = (c->nx + quantum - 1) / quantum * quantum + skew * 64;
-    c->rows_store = c->is2d() ? (size_t)c->sn + 2 : ((size_t)c->sn + 2) * c->ny;
+    c->rows_store = c->is2d() ? (size_t)c->sn + 2 * c->halo : ((size_t)c->sn + 2) * c->ny;
     c->elems = c->rows_store * c->pitch;
+    c->lead = (size_t)(c->halo - 1) * c->pitch;
 
     int rc = 0;
-    const bool two_h = c->kernel == FDTD_KERNEL_FUSED;
+    const bool two_h = c->one_pass();
+    const int levels = c->kernel == FDTD_KERNEL_MULTISTEP ? 4 : 2;
     for (int k = 0; k < 3 && !rc; ++k) {
         const bool used_h = c->is2d() ? k < 2 : true;  // hx, hy
         const bool used_ed = c->is2d() ? k == 2 : true; // dz, ez
@@ -550,7 +660,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             rc = alloc_field(c, &c->h[k][0]);
             if (!rc && two_h) rc = alloc_field(c, &c->h[k][1]);
         }
-        for (int l = 0; l < 2 && used_ed && !rc; ++l) {
+        for (int l = 0; l < levels && used_ed && !rc; ++l) {
             rc = alloc_field(c, &c->e[k][l]);
             if (!rc) rc = alloc_field(c, &c->d[k][l]);
         }
@@ -558,7 +668,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     if (rc) return rc;
     uint8_t *code_base = nullptr;
     if ((rc = dev_alloc(c, &code_base, c->elems + 2 * kSlack))) return rc;
-    c->code = code_base + kSlack;
+    c->code = code_base + kSlack + c->lead;
     if ((rc = dev_alloc(c, &c->table, (size_t)FDTD_MAX_CODES))) return rc;
 
     // Every code maps to the defaults until a spec table is loaded.
@@ -723,12 +833,16 @@ int fdtd_setup_mur_from_materials(fdtd_ctx *c)
 int fdtd_step(fdtd_ctx *c, int nsteps)
 {
     if (use_device(c)) return -10;
-    for (int i = 0; i < nsteps; ++i) {
-        int rc = step_once(c);
+    for (int i = 0; i < nsteps;) {
+        const bool pass = c->kernel == FDTD_KERNEL_MULTISTEP && nsteps - i >= c->tb_steps;
+        int rc = pass ? pass_once(c) : step_once(c);
         if (rc) return rc;
+        i += pass ? c->tb_steps : 1;
     }
     return 0;
 }
+
+int fdtd_steps_per_pass(const fdtd_ctx *c) { return c->kernel == FDTD_KERNEL_MULTISTEP ? c->tb_steps : 1; }
 
 int fdtd_sync(fdtd_ctx *c)
 {
@@ -766,6 +880,7 @@ int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
 
 const char *fdtd_sweep_kernel_name(const fdtd_ctx *c)
 {
+    if (c->is2d() && c->kernel == FDTD_KERNEL_MULTISTEP) return sweep2d_tb_kernel_name();
     if (c->is2d()) return c->kernel == FDTD_KERNEL_FUSED ? sweep2d_kernel_name() : de2d_kernel_name();
     return c->kernel == FDTD_KERNEL_FUSED ? sweep3d_kernel_name() : de3d_kernel_name();
 }
@@ -951,8 +1066,8 @@ int fdtd_halo_put(fdtd_ctx *c, int side, const float *src, size_t count)
 namespace {
 
 struct CheckpointHeader {
-    char magic[8]; // "FDTDCKP1"
-    int32_t mode, kernel, ecoef, nx, ny, nz, s0, sn, pitch, cur, hgen, narrays;
+    char magic[8]; // "FDTDCKP2"
+    int32_t mode, kernel, ecoef, nx, ny, nz, s0, sn, pitch, cur, hgen, narrays, pair, halo;
     int64_t step, elems;
 };
 
@@ -961,11 +1076,11 @@ std::vector<float *> state_arrays(fdtd_ctx *c)
     std::vector<float *> v;
     for (int k = 0; k < 3; ++k)
         for (int g = 0; g < 2; ++g)
-            if (c->h[k][g]) v.push_back(c->h[k][g]);
+            if (c->h[k][g]) v.push_back(c->h[k][g] - c->lead);
     for (int k = 0; k < 3; ++k)
-        for (int l = 0; l < 2; ++l) {
-            if (c->d[k][l]) v.push_back(c->d[k][l]);
-            if (c->e[k][l]) v.push_back(c->e[k][l]);
+        for (int l = 0; l < 4; ++l) {
+            if (c->d[k][l]) v.push_back(c->d[k][l] - c->lead);
+            if (c->e[k][l]) v.push_back(c->e[k][l] - c->lead);
         }
     return v;
 }
@@ -974,7 +1089,7 @@ CheckpointHeader header_of(fdtd_ctx *c, int narrays)
 {
     CheckpointHeader h;
     std::memset(&h, 0, sizeof h);
-    std::memcpy(h.magic, "FDTDCKP1", 8);
+    std::memcpy(h.magic, "FDTDCKP2", 8);
     h.mode = c->mode;
     h.kernel = c->kernel;
     h.ecoef = c->ecoef;
@@ -986,6 +1101,8 @@ CheckpointHeader header_of(fdtd_ctx *c, int narrays)
     h.pitch = c->pitch;
     h.cur = c->cur;
     h.hgen = c->hgen;
+    h.pair = c->pair;
+    h.halo = c->halo;
     h.narrays = narrays;
     h.step = c->step;
     h.elems = (int64_t)c->elems;
@@ -1047,7 +1164,7 @@ int fdtd_checkpoint_load(fdtd_ctx *c, const char *path)
     }
     if (h.mode != want.mode || h.kernel != want.kernel || h.ecoef != want.ecoef || h.nx != want.nx ||
         h.ny != want.ny || h.nz != want.nz || h.s0 != want.s0 || h.sn != want.sn || h.pitch != want.pitch ||
-        h.narrays != want.narrays || h.elems != want.elems) {
+        h.narrays != want.narrays || h.elems != want.elems || h.halo != want.halo) {
         std::fclose(f);
         set_error("fdtd_checkpoint_load: the checkpoint was written by a context of another shape "
                   "(grid, slab, mode, kernel or ecoef differ)");
@@ -1070,6 +1187,7 @@ int fdtd_checkpoint_load(fdtd_ctx *c, const char *path)
         }
     std::fclose(f);
     c->cur = h.cur;
+    c->pair = h.pair;
     c->hgen = h.hgen;
     c->step = h.step;
     c->probe_first = c->step;

@@ -77,6 +77,31 @@ struct Sweep2D {
     SourceList src;
 };
 
+// The multi-step 2-D sweep (sweep2d_tb.hip): K time steps in one pass over memory.
+constexpr int kMaxStepsPerPass = 4;
+struct SweepTB {
+    Grid2D g;
+    const float *hx_r, *hy_r;   // H, read generation (step n - 1/2)
+    float *hx_w, *hy_w;         // H, write generation (step n + K - 1/2)
+    const float *ez_n, *ez_p;   // E levels n, n-1
+    const float *dz_n, *dz_p;   // D levels n, n-1
+    float *ez_a, *ez_b;         // receive E levels n+K-1, n+K (no aliasing with the inputs: the halo
+    float *dz_a, *dz_b;         //   rows of a wave are owned -- and overwritten -- by its neighbours)
+    const uint8_t *code;
+    const MatEntry *table;
+    MatEntry one;
+    int ntab;
+    SourceList src;                       // src.jz is not used
+    float jz[kMaxStepsPerPass];           // source sample of each step of the pass
+    const float *rpx0, *rpxe, *rpy0, *rpye; // Mur planes, as in Mur2D
+    float dx, dy, mu0, eps0;
+    ProbeList probes;
+    float *ring;                          // probe ring, nullptr = no probes
+    int slot[kMaxStepsPerPass];           // ring slots of the intermediate levels 1 .. K-1
+    int rows;                             // owned rows per wave
+    int strips;                           // waves across a row (62 owned words each)
+};
+
 struct Mur2D {
     Grid2D g;
     float *ez_t;       // level n+1
@@ -145,6 +170,8 @@ struct Probe2D {
     ProbeList p;
     float *ring;
     int slot;
+    int nmid;                            // earlier slots the multi-step sweep filled for the probes held here
+    int mid_slot[kMaxStepsPerPass];
 };
 
 struct Probe3D {
@@ -159,6 +186,8 @@ struct Probe3D {
 void launch_h2d(const Sweep2D &a, void *stream);
 void launch_de2d(const Sweep2D &a, void *stream);
 void launch_sweep2d(const Sweep2D &a, void *stream);
+void launch_sweep2d_tb(const SweepTB &a, int steps, void *stream);
+const char *sweep2d_tb_kernel_name();
 void launch_sweep3d(const Fused3D &a, void *stream);
 void launch_mur2d(const Mur2D &a, void *stream);
 void launch_h3d(const Sweep3D &a, void *stream);

@@ -270,6 +270,14 @@ __global__ void fdtd2d_probe(const Probe2D a)
         v[2] = a.dz[o];
         v[3] = a.ez[o];
     }
+    else {
+        // not on this slab: the multi-step sweep wrote nothing for it into the earlier slots
+        for (int m = 0; m < a.nmid; ++m) {
+            float *mid = a.ring + ((size_t)a.mid_slot[m] * FDTD_MAX_PROBES + i) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mid[c] = 0.f;
+        }
+    }
     float *dst = a.ring + ((size_t)a.slot * FDTD_MAX_PROBES + i) * 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) dst[c] = v[c];

@@ -1,0 +1,299 @@
+// fdtd2d_sweep_tb: K time steps of the 2-D TMz grid in ONE pass over memory.
+//
+// A one-step sweep has to move every live array through HBM once per step
+// (41 bytes per cell).  Here a wave carries a window of rows through K chained
+// stages in registers -- stage s applies updateHField + updateDField +
+// updateSources + updateEField (fdtd_calculations.cu:32-213) and the Mur update
+// (fdtd_calculations.cu:369-427) of step n+s to a row as soon as stage s-1 has
+// produced the rows it depends on -- so a pass reads levels n, n-1 and H once
+// (25 bytes per cell) and writes levels n+K, n+K-1 and H once (24 bytes per
+// cell) whatever K is.  The arithmetic per cell and step is the same sequence
+// of IEEE operations as in the one-step sweep.
+//
+// Work decomposition.  A wave owns 62 consecutive 16-byte words (248 columns)
+// of `rows` consecutive rows; lane 0 and lane 63 hold the words to the left and
+// right of them, whose level-s values are only valid in their 4 - s columns next
+// to the owned words (one column is lost per step, hence K <= 4).  The wave
+// marches upwards; in iteration j stage s works on row j - (s - 1), so the
+// pipeline is primed K rows below the first owned row and drained K - 1 rows
+// above the last: rows outside the owned window are recomputed, not
+// communicated.  Because neighbouring waves re-read the rows a wave writes, the
+// output levels live in arrays of their own (no in-place update), and H has a
+// read and a write generation.
+//
+// Mur.  Levels 1 .. K-1 get their boundary values in registers: the x faces
+// right after the E update of the row, the y = 0 row one iteration later (it
+// needs the new row 1), the y = ny-1 row from the carried row ny-2.  Level K is
+// stored as the E update leaves it; the ordinary Mur kernel finishes it.
+#include "device_math.h"
+
+namespace fdtd {
+
+namespace {
+
+// Level s-1 of one row: what stage s consumes.
+struct Level {
+    f4 ez, hx, hy, dz; // level s-1
+    f4 ezp, dzp;       // level s-2
+    unsigned cd;       // four material codes
+};
+
+struct StageOut {
+    f4 ez, hx, hy, dz;
+};
+
+template <int K, bool ONE>
+__global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
+{
+    constexpr int OWN = 62;
+    const Grid2D &g = a.g;
+    const int lane = threadIdx.x & 63;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = (int)(wv % a.strips);
+    const int y0 = (int)(wv / a.strips) * a.rows;
+    if (y0 >= g.nyl) return;
+    const int y1 = min(y0 + a.rows, g.nyl);
+    const int w = strip * OWN - 1 + lane; // word of the row held by this lane
+    const int x4 = w * 4;
+    const bool act = w >= 0 && x4 < g.nx;
+    const bool own = act && lane >= 1 && lane <= OWN;
+    const long pitch = g.pitch;
+
+    bool m_hx[4], m_hy[4], m_ez[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int x = x4 + i;
+        m_hx[i] = x >= 1 && x <= g.nx - 2; // also the dz guard and the x range of the y-face Mur cells
+        m_hy[i] = x >= 0 && x <= g.nx - 2;
+        m_ez[i] = x >= 1 && x <= g.nx - 1;
+    }
+    // the x = nx-1 Mur cell: word and component, and whether this wave holds it
+    const int xe_w = (g.nx - 1) >> 2, xe_c = (g.nx - 1) & 3;
+    const int w_first = strip * OWN - 1;
+    const bool wave_xe = xe_w >= w_first && xe_w < w_first + 64;
+
+    // sources and probes inside the window of this wave (wave-uniform masks)
+    const int jlo = y0 - K, jhi = y1 + K - 2;
+    unsigned srcmask = 0, prbmask = 0;
+    for (int s = 0; s < a.src.count; ++s) {
+        const int js = a.src.y[s] - g.gy0, ws = a.src.x[s] >> 2;
+        if (ws >= w_first && ws < w_first + 64 && js >= jlo && js <= jhi) srcmask |= 1u << s;
+    }
+    if (K > 1 && a.ring) {
+        for (int s = 0; s < a.probes.count; ++s) {
+            const int js = a.probes.y[s] - g.gy0, ws = a.probes.x[s] >> 2;
+            if (ws > w_first && ws <= w_first + OWN && js >= y0 && js < y1 && a.probes.x[s] >= 0 &&
+                a.probes.x[s] < g.nx)
+                prbmask |= 1u << s;
+        }
+    }
+
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+
+    // One stage: level s-1 of row r (and ez of row r + 1, hx of level s of row r - 1) -> level s of row r.
+    auto stage = [&](const Level &in, const f4 &ezu, const f4 &hxb, int r, float jz) -> StageOut {
+        const int y = g.gy0 + r;
+        const bool gy_hx = y >= 0 && y <= g.gny - 2;
+        const bool gy_in = y >= 1 && y <= g.gny - 2;
+        const bool gy_ez = y >= 0 && y <= g.gny - 1;
+        StageOut o;
+        const float e_right = __shfl_down(in.ez.x, 1);
+        const float er[4] = {in.ez.y, in.ez.z, in.ez.w, e_right};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o.hx[i] = (gy_hx && m_hx[i]) ? in.hx[i] - g.kh_y * (ezu[i] - in.ez[i]) : in.hx[i];
+            o.hy[i] = (gy_in && m_hy[i]) ? in.hy[i] + g.kh_x * (er[i] - in.ez[i]) : in.hy[i];
+        }
+        const float hy_left = __shfl_up(o.hy.w, 1);
+        const float hl[4] = {hy_left, o.hy.x, o.hy.y, o.hy.z};
+
+        unsigned srcflag = 0;
+        if (srcmask) {
+            for (int s = 0; s < a.src.count; ++s) {
+                if (!((srcmask >> s) & 1u) || a.src.y[s] - g.gy0 != r) continue;
+                if ((a.src.x[s] >> 2) == w) srcflag |= 1u << (a.src.x[s] & 3);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float v = (in.dz[i] + g.cx * (o.hy[i] - hl[i])) - g.cy * (o.hx[i] - hxb[i]);
+            float dn = (gy_in && m_hx[i]) ? v : in.dzp[i];
+            if ((srcflag >> i) & 1u) dn = v - jz;
+            o.dz[i] = dn;
+        }
+
+        bool uniform = true;
+        MatEntry mu = a.one;
+        if (!ONE) {
+            const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)in.cd) & 0xffu;
+            uniform = __all(in.cd == c0 * 0x01010101u);
+            if (uniform) mu = a.table[c0];
+        }
+        if (uniform) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                o.ez[i] = (gy_ez && m_ez[i]) ? e_update(mu, g.dt, in.ez[i], in.ezp[i], o.dz[i], in.dz[i], in.dzp[i])
+                                             : in.ezp[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const MatEntry m = a.table[(in.cd >> (8 * i)) & 0xffu];
+                o.ez[i] = (gy_ez && m_ez[i]) ? e_update(m, g.dt, in.ez[i], in.ezp[i], o.dz[i], in.dz[i], in.dzp[i])
+                                             : in.ezp[i];
+            }
+        }
+        return o;
+    };
+
+    // Mur on the x faces of a freshly computed row (level s), fdtd_calculations.cu:369-395.
+    auto mur_x = [&](f4 &et, const f4 &es, int r) {
+        const int y = g.gy0 + r;
+        const bool yok = y >= 1 && y <= g.gny - 2;
+        if (w == 0 && yok)
+            et.x = mur_face(g.dt, a.dx, a.mu0, a.eps0, a.rpx0[(size_t)y * 2], a.rpx0[(size_t)y * 2 + 1], et.y, es.y,
+                            es.x);
+        if (wave_xe) {
+            const float t_prev = __shfl_up(et.w, 1), s_prev = __shfl_up(es.w, 1);
+            if (w == xe_w && yok) {
+                const float r_here = a.rpxe[(size_t)y * 2 + 1], r_in = a.rpxe[(size_t)y * 2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i == xe_c) {
+                        const float t_in = i ? et[i ? i - 1 : 0] : t_prev, s_in = i ? es[i ? i - 1 : 0] : s_prev;
+                        et[i] = mur_face(g.dt, a.dx, a.mu0, a.eps0, r_here, r_in, t_in, s_in, es[i]);
+                    }
+            }
+        }
+    };
+    // Mur on the y faces, fdtd_calculations.cu:401-427: `here` is the face row, `in` the row next to it.
+    auto mur_y = [&](f4 &et_here, const f4 &et_in, const f4 &es_in, const f4 &es_here, const float *rp, bool high) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!m_hx[i]) continue;
+            const int x = x4 + i;
+            const float r_face = high ? rp[g.nx + x] : rp[x], r_next = high ? rp[x] : rp[g.nx + x];
+            et_here[i] = mur_face(g.dt, a.dy, a.mu0, a.eps0, r_face, r_next, et_in[i], es_in[i], es_here[i]);
+        }
+    };
+
+    auto record = [&](const Level &v, int r, int slot) {
+        for (int s = 0; s < a.probes.count; ++s) {
+            if (!((prbmask >> s) & 1u) || a.probes.y[s] - g.gy0 != r || (a.probes.x[s] >> 2) != w) continue;
+            const int i = a.probes.x[s] & 3;
+            float *dst = a.ring + ((size_t)slot * FDTD_MAX_PROBES + s) * 4;
+            float hx = v.hx.x, hy = v.hy.x, dz = v.dz.x, ez = v.ez.x;
+#pragma unroll
+            for (int q = 1; q < 4; ++q)
+                if (q == i) hx = v.hx[q], hy = v.hy[q], dz = v.dz[q], ez = v.ez[q];
+            dst[0] = hx;
+            dst[1] = hy;
+            dst[2] = dz;
+            dst[3] = ez;
+        }
+    };
+
+    // Everything a wave loads for one row (levels n, n-1 and H), and ez^n of the row above.
+    struct RowIn {
+        f4 hx, hy, ezp, dz, dzp, ezu;
+        unsigned cd;
+    };
+    auto load = [&](RowIn &r, int j) {
+        const long off = (long)(j + 1) * pitch + x4;
+        r.hx = act ? ld4_stream(a.hx_r + off) : zero;
+        r.hy = act ? ld4_stream(a.hy_r + off) : zero;
+        r.ezp = act ? ld4_stream(a.ez_p + off) : zero;
+        r.dz = act ? ld4_stream(a.dz_n + off) : zero;
+        r.dzp = act ? ld4_stream(a.dz_p + off) : zero;
+        r.ezu = act ? ld4_stream(a.ez_n + off + pitch) : zero;
+        r.cd = act ? *(const unsigned *)(a.code + off) : 0u;
+    };
+
+    Level c[K + 1]; // c[s]: level s-1 of the row stage s works on next (c[1] comes from memory)
+    f4 hxb[K + 1];  // hxb[s]: level-s hx of the row below it
+#pragma unroll
+    for (int s = 0; s <= K; ++s) {
+        c[s].ez = c[s].hx = c[s].hy = c[s].dz = c[s].ezp = c[s].dzp = zero;
+        c[s].cd = 0;
+        hxb[s] = zero;
+    }
+
+    RowIn cur;
+    load(cur, jlo);
+    f4 ezc = act ? ld4_stream(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
+
+    for (int j = jlo; j <= jhi; ++j) {
+        RowIn nxt;
+        if (j < jhi) load(nxt, j + 1);
+
+        c[1].ez = ezc;
+        c[1].hx = cur.hx;
+        c[1].hy = cur.hy;
+        c[1].dz = cur.dz;
+        c[1].ezp = cur.ezp;
+        c[1].dzp = cur.dzp;
+        c[1].cd = cur.cd;
+        f4 ezu = cur.ezu;
+        Level keep[K + 1];
+#pragma unroll
+        for (int s = 1; s <= K; ++s) {
+            const int r = j - (s - 1);
+            StageOut o = stage(c[s], ezu, hxb[s], r, a.jz[s - 1]);
+            if (s < K) {
+                const int y = g.gy0 + r;
+                mur_x(o.ez, c[s].ez, r);
+                if (y == g.gny - 1) mur_y(o.ez, c[s + 1].ez, c[s + 1].ezp, c[s].ez, a.rpye, true);
+                if (y == 1) mur_y(c[s + 1].ez, o.ez, c[s].ez, c[s + 1].ezp, a.rpy0, false);
+                // c[s + 1] now holds the final level s of row r - 1
+                if (prbmask && own && r - 1 >= y0 && r - 1 < y1) record(c[s + 1], r - 1, a.slot[s]);
+                keep[s + 1].ez = o.ez;
+                keep[s + 1].hx = o.hx;
+                keep[s + 1].hy = o.hy;
+                keep[s + 1].dz = o.dz;
+                keep[s + 1].ezp = c[s].ez;
+                keep[s + 1].dzp = c[s].dz;
+                keep[s + 1].cd = c[s].cd;
+            } else if (own && r >= y0 && r < y1) {
+                const long q = (long)(r + 1) * pitch + x4;
+                st4_stream(a.hx_w + q, o.hx);
+                st4_stream(a.hy_w + q, o.hy);
+                st4_stream(a.dz_b + q, o.dz);
+                st4_stream(a.ez_b + q, o.ez);
+                st4_stream(a.dz_a + q, c[K].dz);
+                st4_stream(a.ez_a + q, c[K].ez);
+            }
+            hxb[s] = o.hx;
+            ezu = o.ez;
+        }
+#pragma unroll
+        for (int s = 2; s <= K; ++s) c[s] = keep[s];
+        ezc = cur.ezu;
+        cur = nxt;
+    }
+}
+
+template <int K> void launch_k(const SweepTB &a, hipStream_t stream)
+{
+    const long bands = (a.g.nyl + a.rows - 1) / a.rows;
+    const long waves = bands * a.strips;
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (a.ntab == 1)
+        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false>), grid, dim3(256), 0, stream, a);
+}
+
+} // namespace
+
+void launch_sweep2d_tb(const SweepTB &a, int steps, void *stream)
+{
+    switch (steps) {
+    case 2: launch_k<2>(a, (hipStream_t)stream); break;
+    case 3: launch_k<3>(a, (hipStream_t)stream); break;
+    case 4: launch_k<4>(a, (hipStream_t)stream); break;
+    default: launch_k<1>(a, (hipStream_t)stream); break;
+    }
+}
+
+const char *sweep2d_tb_kernel_name() { return "fdtd2d_sweep_tb"; }
+
+} // namespace fdtd

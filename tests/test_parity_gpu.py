@@ -79,7 +79,8 @@ def test_3d_mur_from_loaded_materials(oracle):
 
 # ------------------------------------------------------------------ 2-D TMz
 
-KERNELS = [B.KERNEL_FUSED, B.KERNEL_SPLIT]
+MS2, MS3, MS4 = (B.KERNEL_MULTISTEP, 2), (B.KERNEL_MULTISTEP, 3), (B.KERNEL_MULTISTEP, 4)
+KERNELS = [B.KERNEL_FUSED, B.KERNEL_SPLIT, MS2, MS3, MS4]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -154,7 +155,7 @@ def test_2d_upsampled_pgm_matches_oracle_on_repeated_codes(oracle):
 
 # ------------------------------------------------------------------ slabs
 
-@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("kernel", KERNELS[:2])
 @pytest.mark.parametrize("world", [2, 3])
 def test_2d_slabs_equal_whole_grid(oracle, kernel, world):
     """world slabs on one GPU, halos staged through the host after every step:

@@ -1,0 +1,113 @@
+// Feasibility probe: the memory access pattern of a two-steps-per-pass 2-D sweep
+// (wave = 64 float4 words wide, 60 of them owned, marching R + 2 rows for R owned rows;
+// 6 arrays read, 6 written per pass) with placeholder arithmetic.  Prints ms per pass
+// and the equivalent cell-updates/s for a 16384 x 16384 grid.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct Arrays {
+    const f4 *hx, *hy, *ez0, *ezm, *dz0, *dzm;   // read
+    f4 *hxn, *hyn, *ez1, *ez2, *dz1, *dz2;       // written (separate arrays: halo rows are re-read by neighbours)
+    int words;      // float4 words per row
+    int rows;
+    int strips;     // waves across a row
+};
+
+template <bool NT> __device__ inline f4 ld(const f4 *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ inline void st(f4 v, f4 *p) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+__device__ inline f4 shl(f4 v) { f4 r; r.x = v.y; r.y = v.z; r.z = v.w; r.w = __shfl_down(v.x, 1); return r; }
+__device__ inline f4 shr(f4 v) { f4 r; r.y = v.x; r.z = v.y; r.w = v.z; r.x = __shfl_up(v.w, 1); return r; }
+
+template <int R, bool NT> __global__ __launch_bounds__(256) void tb2(Arrays a)
+{
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int strip = (int)(wave % a.strips);
+    const long band = wave / a.strips;
+    const long y0 = band * R;
+    if (y0 >= a.rows) return;
+    int w = strip * 60 - 2 + lane;
+    const bool inrow = w >= 0 && w < a.words;
+    const bool own = lane >= 2 && lane < 62 && inrow;
+    if (!inrow) w = w < 0 ? 0 : a.words - 1;
+    // carried state of the previous row
+    f4 hx1p = {0, 0, 0, 0}, hy1p = hx1p, ez1p = hx1p, ez0p = hx1p, dz1p = hx1p, dz0p = hx1p, hx2pp = hx1p;
+    long y = y0 - 1;
+    if (y < 0) y = 0;
+    f4 ez0 = ld<false>(a.ez0 + y * a.words + w);
+    for (long j = y0 - 1; j <= y0 + R && j < a.rows; ++j) {
+        const long row = j < 0 ? 0 : j;
+        const size_t o = (size_t)row * a.words + w;
+        const long up = row + 1 < a.rows ? row + 1 : row;
+        const f4 ez0u = ld<false>(a.ez0 + (size_t)up * a.words + w);
+        const f4 hx = ld<NT>(a.hx + o), hy = ld<NT>(a.hy + o), ezm = ld<NT>(a.ezm + o), dz0 = ld<NT>(a.dz0 + o),
+                 dzm = ld<NT>(a.dzm + o);
+        // step 1 on this row
+        const f4 hx1 = hx - 0.5f * (ez0u - ez0);
+        const f4 hy1 = hy + 0.5f * (shl(ez0) - ez0);
+        const f4 dz1 = dz0 + 0.5f * (hy1 - shr(hy1)) - 0.5f * (hx1 - hx1p);
+        const f4 ez1 = 0.3f * ez0 - 0.2f * ezm + 0.9f * dz1 - 0.4f * dz0 + 0.1f * dzm;
+        // step 2 on the previous row
+        const f4 hx2 = hx1p - 0.5f * (ez1 - ez1p);
+        const f4 hy2 = hy1p + 0.5f * (shl(ez1p) - ez1p);
+        const f4 dz2 = dz1p + 0.5f * (hy2 - shr(hy2)) - 0.5f * (hx2 - hx2pp);
+        const f4 ez2 = 0.3f * ez1p - 0.2f * ez0p + 0.9f * dz2 - 0.4f * dz1p + 0.1f * dz0p;
+        if (own && j - 1 >= y0 && j - 1 < y0 + R) {
+            const size_t q = (size_t)(j - 1) * a.words + w;
+            st<NT>(hx2, a.hxn + q);
+            st<NT>(hy2, a.hyn + q);
+            st<NT>(ez1p, a.ez1 + q);
+            st<NT>(ez2, a.ez2 + q);
+            st<NT>(dz1p, a.dz1 + q);
+            st<NT>(dz2, a.dz2 + q);
+        }
+        hx2pp = hx2; hx1p = hx1; hy1p = hy1; ez1p = ez1; ez0p = ez0; dz1p = dz1; dz0p = dz0;
+        ez0 = ez0u;
+    }
+}
+
+template <int R, bool NT> void run(Arrays a)
+{
+    const long bands = (a.rows + R - 1) / R;
+    const long waves = bands * a.strips;
+    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((tb2<R, NT>), dim3(blocks), dim3(256), 0, 0, a);
+    hipEventRecord(e0);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((tb2<R, NT>), dim3(blocks), dim3(256), 0, 0, a);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= 5;
+    printf("R=%2d nt=%d: %.3f ms per 2-step pass, %.1f Gcell-updates/s\n", R, (int)NT, ms,
+           2.0 * a.words * 4 * a.rows / ms / 1e6);
+    fflush(stdout);
+}
+
+int main(int argc, char **argv)
+{
+    const int n = argc > 1 ? atoi(argv[1]) : 16384;
+    const size_t cells = (size_t)n * n;
+    float *buf[12];
+    for (auto &b : buf) {
+        hipMalloc((void **)&b, cells * 4 + 4096);
+        hipMemset(b, 0, cells * 4 + 4096);
+    }
+    Arrays a;
+    a.hx = (f4 *)buf[0]; a.hxn = (f4 *)buf[1];
+    a.hy = (f4 *)buf[2]; a.hyn = (f4 *)buf[3];
+    a.ez0 = (f4 *)buf[4]; a.ezm = (f4 *)buf[5]; a.ez1 = (f4 *)buf[6]; a.ez2 = (f4 *)buf[7];
+    a.dz0 = (f4 *)buf[8]; a.dzm = (f4 *)buf[9]; a.dz1 = (f4 *)buf[10]; a.dz2 = (f4 *)buf[11];
+    a.words = n / 4;
+    a.rows = n;
+    a.strips = (a.words + 59) / 60;
+    run<4, true>(a); run<8, true>(a); run<16, true>(a); run<32, true>(a); run<64, true>(a);
+    run<8, false>(a); run<16, false>(a); run<32, false>(a);
+    return 0;
+}

@@ -98,6 +98,12 @@ struct fdtd_ctx {
     Comm *comm = nullptr;
     int rank = 0, world = 1;
 
+    // MULTISTEP slabs: deep halos (tb_steps rows of every live array per side)
+    float *halo_send[2] = {}, *halo_recv[2] = {};
+    bool halo_stale = true; // set by everything that changes the state behind the stepper's back
+    bool deep() const { return kernel == FDTD_KERNEL_MULTISTEP; }
+    size_t deep_count() const { return (size_t)6 * tb_steps * nx + ((size_t)tb_steps * nx + 3) / 4; }
+
     bool is2d() const { return mode == FDTD_MODE_2D_TMZ; }
     bool one_pass() const { return kernel == FDTD_KERNEL_FUSED || kernel == FDTD_KERNEL_MULTISTEP; }
     // level 0 = newest, 1 = previous
@@ -280,9 +286,62 @@ float *halo_rows(fdtd_ctx *c, int comp, int side, bool halo)
 
 void record_probes(fdtd_ctx *c, int mid);
 
+int ensure_deep_buffers(fdtd_ctx *c)
+{
+    if (c->halo_send[0]) return 0;
+    for (int s = 0; s < 2; ++s) {
+        int rc = dev_alloc(c, &c->halo_send[s], c->deep_count());
+        if (!rc) rc = dev_alloc(c, &c->halo_recv[s], c->deep_count());
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// Pack the boundary rows of the sides in `sides` into halo_send, or unpack halo_recv into the halo rows.
+int deep_halo_kernel(fdtd_ctx *c, int sides, bool unpack)
+{
+    int rc = ensure_deep_buffers(c);
+    if (rc) return rc;
+    HaloDeep a;
+    a.arr[0] = c->h[0][c->hgen];
+    a.arr[1] = c->h[1][c->hgen];
+    a.arr[2] = c->E(2, 0);
+    a.arr[3] = c->E(2, 1);
+    a.arr[4] = c->D(2, 0);
+    a.arr[5] = c->D(2, 1);
+    a.code = c->code;
+    for (int s = 0; s < 2; ++s) a.buf[s] = unpack ? c->halo_recv[s] : c->halo_send[s];
+    a.nx = c->nx;
+    a.pitch = c->pitch;
+    a.nyl = c->sn;
+    a.depth = c->tb_steps;
+    a.sides = sides;
+    a.unpack = unpack ? 1 : 0;
+    launch_halo_deep(a, c->stream);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 int exchange_halos_rccl(fdtd_ctx *c)
 {
     if (!c->comm || c->world == 1) return 0;
+    if (c->deep()) {
+        const int lower = c->rank - 1, upper = c->rank + 1;
+        const int sides = (lower >= 0 ? 1 : 0) | (upper < c->world ? 2 : 0);
+        int rc = deep_halo_kernel(c, sides, false);
+        if (rc) return rc;
+        rc = comm_group_start(c->comm);
+        const int peer[2] = {lower, upper};
+        for (int s = 0; s < 2 && rc == 0; ++s) {
+            if (!((sides >> s) & 1)) continue;
+            rc = comm_send(c->comm, c->halo_send[s], c->deep_count(), peer[s], c->stream);
+            if (rc == 0) rc = comm_recv(c->comm, c->halo_recv[s], c->deep_count(), peer[s], c->stream);
+        }
+        const int rc2 = comm_group_end(c->comm);
+        if (rc || rc2) return rc ? rc : rc2;
+        c->halo_stale = false;
+        return deep_halo_kernel(c, sides, true);
+    }
     const size_t count = c->is2d() ? (size_t)c->nx : (size_t)c->ny * c->pitch;
     const int c0 = c->is2d() ? 2 : 0;
     const int lower = c->rank - 1, upper = c->rank + 1;
@@ -586,7 +645,20 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         return -3;
     }
     c->ecoef = opt->ecoef;
-    c->kernel = opt->kernel == FDTD_KERNEL_AUTO ? FDTD_KERNEL_FUSED : opt->kernel;
+    c->kernel = opt->kernel;
+    if (c->kernel == FDTD_KERNEL_AUTO) {
+        // 2-D: four steps per pass when the 49 bytes per cell it keeps resident fit, else one
+        c->kernel = FDTD_KERNEL_FUSED;
+        if (c->is2d()) {
+            size_t free_b = 0, total_b = 0;
+            (void)hipSetDevice(opt->device);
+            const size_t rows = (size_t)(opt->slab_count > 0 ? opt->slab_count : p->ny) + 2 * kMaxStepsPerPass;
+            const double need = 49.0 * (double)rows * (double)((p->nx + 63) / 64 * 64) * 1.03 + 64e6;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > need &&
+                (opt->slab_count <= 0 || opt->slab_count >= kMaxStepsPerPass))
+                c->kernel = FDTD_KERNEL_MULTISTEP;
+        }
+    }
     if (c->kernel != FDTD_KERNEL_SPLIT && c->kernel != FDTD_KERNEL_FUSED && c->kernel != FDTD_KERNEL_MULTISTEP) {
         set_error("unknown kernel selection");
         return -3;
@@ -596,7 +668,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             set_error("FDTD_KERNEL_MULTISTEP exists for the 2-D TMz mode only");
             return -3;
         }
-        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : 2;
+        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : kMaxStepsPerPass;
         if (c->tb_steps < 2 || c->tb_steps > kMaxStepsPerPass) {
             set_error("steps_per_pass must be 2, 3 or 4");
             return -3;
@@ -609,6 +681,10 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     c->sn = opt->slab_count > 0 ? opt->slab_count : c->gn;
     if (c->s0 < 0 || c->sn < 2 || c->s0 + c->sn > c->gn) {
         set_error("slab must hold at least 2 rows inside the grid");
+        return -3;
+    }
+    if (c->kernel == FDTD_KERNEL_MULTISTEP && c->sn != c->gn && c->sn < c->tb_steps) {
+        set_error("a slab of the multi-step mode must hold at least steps_per_pass rows");
         return -3;
     }
     c->chunk_rows = opt->chunk_rows > 0 ? opt->chunk_rows : 1;
@@ -733,6 +809,7 @@ int fdtd_set_codes(fdtd_ctx *c, const uint8_t *codes, size_t count)
     }
     if (use_device(c)) return -10;
     c->codes_host.assign(codes, codes + count);
+    c->halo_stale = true;
     return upload_codes(c);
 }
 
@@ -765,6 +842,7 @@ int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir
         }
     }
     if ((rc = upload_table(c))) return rc;
+    c->halo_stale = true;
     return upload_codes(c);
 }
 
@@ -833,6 +911,12 @@ int fdtd_setup_mur_from_materials(fdtd_ctx *c)
 int fdtd_step(fdtd_ctx *c, int nsteps)
 {
     if (use_device(c)) return -10;
+    if (c->deep() && c->halo_stale && c->comm && c->world > 1) {
+        // codes, fields or a checkpoint were loaded since the last exchange: the deep halos
+        // (which hold the neighbours' materials and previous levels too) must be refreshed first
+        int rc = exchange_halos_rccl(c);
+        if (rc) return rc;
+    }
     for (int i = 0; i < nsteps;) {
         const bool pass = c->kernel == FDTD_KERNEL_MULTISTEP && nsteps - i >= c->tb_steps;
         int rc = pass ? pass_once(c) : step_once(c);
@@ -928,6 +1012,7 @@ int fdtd_write_field(fdtd_ctx *c, int field, int level, const float *src, size_t
         set_error("fdtd_write_field: count must be the number of cells of the slab");
         return -3;
     }
+    c->halo_stale = true;
     HIPCHK(hipMemcpy2DAsync(v.ptr, (size_t)c->pitch * 4, src, (size_t)c->nx * 4, (size_t)c->nx * 4, v.rows,
                             hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1026,7 +1111,11 @@ int fdtd_read_probes(fdtd_ctx *c, int64_t first_step, int nsteps, float *dst, si
     return 0;
 }
 
-size_t fdtd_halo_count(const fdtd_ctx *c) { return c->is2d() ? (size_t)c->nx : (size_t)3 * c->nx * c->ny; }
+size_t fdtd_halo_count(const fdtd_ctx *c)
+{
+    if (c->deep()) return c->deep_count();
+    return c->is2d() ? (size_t)c->nx : (size_t)3 * c->nx * c->ny;
+}
 
 static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get)
 {
@@ -1035,6 +1124,19 @@ static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get)
         return -3;
     }
     if (use_device(c)) return -10;
+    if (c->deep()) {
+        int rc;
+        if (get) {
+            if ((rc = deep_halo_kernel(c, 1 << side, false))) return rc;
+            HIPCHK(hipMemcpyAsync(host, c->halo_send[side], count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        } else {
+            if ((rc = ensure_deep_buffers(c))) return rc;
+            HIPCHK(hipMemcpyAsync(c->halo_recv[side], host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
+            if ((rc = deep_halo_kernel(c, 1 << side, true))) return rc;
+        }
+        HIPCHK(hipStreamSynchronize(c->stream));
+        return 0;
+    }
     const int c0 = c->is2d() ? 2 : 0;
     const size_t rows = c->is2d() ? 1 : (size_t)c->ny;
     for (int comp = c0; comp < 3; ++comp) {
@@ -1191,6 +1293,7 @@ int fdtd_checkpoint_load(fdtd_ctx *c, const char *path)
     c->hgen = h.hgen;
     c->step = h.step;
     c->probe_first = c->step;
+    c->halo_stale = true;
     return 0;
 }
 
@@ -1209,6 +1312,7 @@ int fdtd_comm_init(fdtd_ctx *c, const char id[128], int rank, int world)
     }
     c->rank = rank;
     c->world = world;
+    c->halo_stale = true;
     return comm_create(id, rank, world, &c->comm);
 }
 
@@ -1219,6 +1323,25 @@ int fdtd_comm_selftest(fdtd_ctx *c)
         return -3;
     }
     if (use_device(c)) return -10;
+    if (c->deep()) {
+        // the packed boundary rows of side 0 -> the receive buffer of side 1, through ncclSend/ncclRecv
+        const size_t n = c->deep_count();
+        int rc = deep_halo_kernel(c, 3, false);
+        if (!rc) rc = comm_group_start(c->comm);
+        if (!rc) rc = comm_send(c->comm, c->halo_send[0], n, c->rank, c->stream);
+        if (!rc) rc = comm_recv(c->comm, c->halo_recv[1], n, c->rank, c->stream);
+        const int rc2 = comm_group_end(c->comm);
+        if (rc || rc2) return rc ? rc : rc2;
+        std::vector<float> a(n), b(n);
+        HIPCHK(hipMemcpyAsync(a.data(), c->halo_send[0], n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(b.data(), c->halo_recv[1], n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (std::memcmp(a.data(), b.data(), n * 4) != 0) {
+            set_error("fdtd_comm_selftest: the received halo block differs from the block sent");
+            return -22;
+        }
+        return 0;
+    }
     // first owned row of the newest E level -> upper halo row, through ncclSend/ncclRecv to this rank
     const int comp = 2;
     const size_t count = c->is2d() ? (size_t)c->nx : (size_t)c->ny * c->pitch;

@@ -164,6 +164,18 @@ struct Fused3D {
     int src_comp[FDTD_MAX_SOURCES];        // which of the word's four cells
 };
 
+// Deep halo exchange of the multi-step mode: `depth` rows of every live array (H, both E and D
+// levels, material codes) next to a slab boundary, packed into / unpacked from one buffer per side:
+// buf[side] = 6 arrays x depth rows x nx floats, then depth x nx code bytes.
+struct HaloDeep {
+    float *arr[6];   // hx, hy, ez newest, ez previous, dz newest, dz previous (local row -1 at storage row 0)
+    uint8_t *code;
+    float *buf[2];   // side 0 = lower neighbour, side 1 = upper neighbour
+    int nx, pitch, nyl, depth;
+    int sides;       // bit mask of the sides to handle
+    int unpack;      // 0: owned rows -> buf; 1: buf -> halo rows
+};
+
 struct Probe2D {
     Grid2D g;
     const float *hx, *hy, *dz, *ez;
@@ -193,6 +205,7 @@ void launch_mur2d(const Mur2D &a, void *stream);
 void launch_h3d(const Sweep3D &a, void *stream);
 void launch_de3d(const Sweep3D &a, void *stream);
 void launch_mur3d(const Mur3D &a, void *stream);
+void launch_halo_deep(const HaloDeep &a, void *stream);
 void launch_probe2d(const Probe2D &a, void *stream);
 void launch_probe3d(const Probe3D &a, void *stream);
 const char *sweep2d_kernel_name();

@@ -283,6 +283,33 @@ __global__ void fdtd2d_probe(const Probe2D a)
     for (int c = 0; c < 4; ++c) dst[c] = v[c];
 }
 
+// blockIdx.y = (side * 7 + array) * depth + row; one thread per column.
+__global__ __launch_bounds__(256) void fdtd2d_halo_deep(const HaloDeep a)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= a.nx) return;
+    const int r = blockIdx.y % a.depth;
+    const int arr = (blockIdx.y / a.depth) % 7;
+    const int side = blockIdx.y / (7 * a.depth);
+    if (!((a.sides >> side) & 1)) return;
+    // packed: the rows a neighbour needs (first / last `depth` owned rows); unpacked: the halo rows
+    const int row = a.unpack ? (side == 0 ? r - a.depth : a.nyl + r) : (side == 0 ? r : a.nyl - a.depth + r);
+    const size_t cell = (size_t)(row + 1) * a.pitch + x; // storage row 0 is local row -1
+    if (arr < 6) {
+        float *slot = a.buf[side] + ((size_t)arr * a.depth + r) * a.nx + x;
+        if (a.unpack)
+            a.arr[arr][cell] = *slot;
+        else
+            *slot = a.arr[arr][cell];
+    } else {
+        uint8_t *slot = (uint8_t *)(a.buf[side] + (size_t)6 * a.depth * a.nx) + (size_t)r * a.nx + x;
+        if (a.unpack)
+            a.code[cell] = *slot;
+        else
+            *slot = a.code[cell];
+    }
+}
+
 __global__ void fdtd3d_probe(const Probe3D a)
 {
     const int i = threadIdx.x;
@@ -338,6 +365,11 @@ void launch_mur3d(const Mur3D &a, void *stream)
 {
     const long total = 2L * a.g.ny * a.g.nzl + 2L * a.g.nx * a.g.nzl + 2L * a.g.nx * a.g.ny;
     hipLaunchKernelGGL(fdtd3d_mur, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S(stream), a);
+}
+
+void launch_halo_deep(const HaloDeep &a, void *stream)
+{
+    hipLaunchKernelGGL(fdtd2d_halo_deep, dim3((a.nx + 255) / 256, 2 * 7 * a.depth), dim3(256), 0, S(stream), a);
 }
 
 void launch_probe2d(const Probe2D &a, void *stream)

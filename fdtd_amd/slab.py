@@ -3,7 +3,8 @@
 The grid is cut along its slowest axis (y in 2-D, z in 3-D).  A slab keeps one
 halo row (plane) of E on either side; after every step each rank sends the
 first and the last row of its newest E level to the neighbours and receives
-theirs into its halo.  H needs no exchange: the one H row below the slab that
+theirs into its halo.  (The multi-step 2-D engine keeps halos as deep as its
+steps per pass, of every array, and exchanges once per pass.)  H needs no exchange: the one H row below the slab that
 the D update reads is recomputed locally from the E halo every step.  The Mur
 faces across the slab axis belong to the first and last rank, sources and
 probes to the rank that holds their row -- the kernels decide that from global
@@ -40,6 +41,11 @@ class SlabRunner:
             raise ValueError("transport must be 'host' or 'rccl'")
         self.engine, self.rank, self.world = engine, rank, world
         self.transport, self.group = transport, group
+        # An engine that advances several steps per pass over memory keeps halos that deep (every
+        # live array, material codes included) and recomputes the rows in them: it exchanges once
+        # per pass, and once before the first pass so that the halos hold the neighbours' state.
+        self.stride = int(getattr(engine, "steps_per_pass", 1))
+        self.primed = self.stride == 1
 
     def exchange(self):
         """Host-staged halo exchange with ranks rank-1 and rank+1."""
@@ -64,6 +70,12 @@ class SlabRunner:
         if self.world == 1 or self.transport == "rccl":
             self.engine.step(nsteps)
             return
-        for _ in range(nsteps):
-            self.engine.step(1)
+        if not self.primed:
             self.exchange()
+            self.primed = True
+        done = 0
+        while done < nsteps:
+            n = self.stride if nsteps - done >= self.stride else 1
+            self.engine.step(n)
+            self.exchange()
+            done += n

@@ -52,11 +52,13 @@ enum { FDTD_MODE_AUTO = 0, FDTD_MODE_3D = 1, FDTD_MODE_2D_TMZ = 2 };
  * per step in vacuum), or d = a + b - sigma*dt^2 (bounded). */
 enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
 /* SPLIT: an H kernel and a fused D+source+E kernel (H updated in place).
- * FUSED: one sweep over memory per step (H double-buffered); the default.
+ * FUSED: one sweep over memory per step (H double-buffered).
  * MULTISTEP (2-D TMz only): one sweep over memory per `steps_per_pass` steps;
  * the same arithmetic per cell and step, 16 more bytes of HBM per cell (E and D
  * keep four arrays instead of two).  fdtd_step(n) runs n / steps_per_pass
- * passes and the remainder as single steps. */
+ * passes and the remainder as single steps.
+ * AUTO: MULTISTEP in 2-D when its arrays fit into the free device memory,
+ * else FUSED. */
 enum { FDTD_KERNEL_AUTO = 0, FDTD_KERNEL_SPLIT = 1, FDTD_KERNEL_FUSED = 2, FDTD_KERNEL_MULTISTEP = 3 };
 
 typedef struct fdtd_options {
@@ -67,7 +69,7 @@ typedef struct fdtd_options {
     int32_t slab_begin;  /* first global row of the slab axis held here (y in 2-D, z in 3-D) */
     int32_t slab_count;  /* rows held; 0 = the whole grid */
     int32_t chunk_rows;  /* rows marched by one workgroup of the fused sweep; 0 = default */
-    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2, 3 or 4; 0 = default (2) */
+    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2, 3 or 4; 0 = default (4) */
     int32_t reserved[8];
 } fdtd_options;
 

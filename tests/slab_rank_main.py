@@ -14,12 +14,14 @@ from fdtd_amd import binding as B
 
 rank, world, port, nx, ny, steps = (int(v) for v in sys.argv[1:7])
 out_dir = sys.argv[7]
+spp = int(sys.argv[8]) if len(sys.argv) > 8 else 0     # > 1: the multi-step engine with that many steps per pass
 os.environ["MASTER_ADDR"] = "127.0.0.1"
 os.environ["MASTER_PORT"] = str(port)
 dist.init_process_group("gloo", rank=rank, world_size=world)
 p = fdtd_amd.make_params(nx, ny, 1, [(nx // 2, ny // 2, 0), (10, ny // 2 - 1, 0)])
 part = fdtd_amd.partition_rows(ny, world)[rank]
-solver = fdtd_amd.Solver(p, ecoef=B.ECOEF_CONSISTENT, slab=part)
+solver = fdtd_amd.Solver(p, ecoef=B.ECOEF_CONSISTENT, slab=part,
+                         kernel=(B.KERNEL_MULTISTEP, spp) if spp > 1 else B.KERNEL_AUTO)
 runner = fdtd_amd.SlabRunner(solver, rank, world, transport="host")
 runner.step(steps)
 for fid in (B.HX, B.HY, B.DZ, B.EZ):

@@ -155,10 +155,11 @@ def test_2d_upsampled_pgm_matches_oracle_on_repeated_codes(oracle):
 
 # ------------------------------------------------------------------ slabs
 
-@pytest.mark.parametrize("kernel", KERNELS[:2])
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("world", [2, 3])
 def test_2d_slabs_equal_whole_grid(oracle, kernel, world):
-    """world slabs on one GPU, halos staged through the host after every step:
+    """world slabs on one GPU, halos staged through the host after every step (every pass
+    of the multi-step kernels, whose halos hold every array steps_per_pass rows deep):
     bit-identical to the single-slab run (and so to the oracle)."""
     nx, ny = 300, 101
     rng = np.random.default_rng(7)
@@ -172,14 +173,21 @@ def test_2d_slabs_equal_whole_grid(oracle, kernel, world):
         for code, row in enumerate(util.RIKEN_LIKE):
             sv.set_material(code, *[float(v) for v in row])
         sv.set_codes(codes[b:b + n])
-    for _ in range(150):
-        whole.step(1)
-        for sv in slabs:
-            sv.step(1)
+    def exchange():
         for r in range(world - 1):          # neighbours r and r + 1
             up, down = slabs[r].halo_get(1), slabs[r + 1].halo_get(0)
             slabs[r + 1].halo_put(0, up)
             slabs[r].halo_put(1, down)
+
+    stride, done, steps = whole.steps_per_pass, 0, 150
+    exchange()                              # the deep halos also carry the neighbours' material codes
+    while done < steps:
+        n = stride if steps - done >= stride else 1
+        whole.step(n)
+        for sv in slabs:
+            sv.step(n)
+        exchange()
+        done += n
     for fid in (B.HX, B.HY, B.DZ, B.EZ):
         full = whole.field(fid)
         got = np.concatenate([sv.field(fid) for sv in slabs], axis=1)
@@ -219,12 +227,22 @@ def test_3d_slabs_equal_whole_grid(oracle, kernel):
 def test_rccl_binding_with_a_one_rank_communicator():
     """The RCCL entry points (dlopen, ncclCommInitRank, grouped ncclSend/ncclRecv on the
     library's stream) on one GPU: a one-rank communicator sends a row to itself."""
-    s = fdtd_amd.Solver(fdtd_amd.make_params(700, 40, 1, [(350, 20, 0)]), ecoef=CON, slab=(0, 40))
+    s = fdtd_amd.Solver(fdtd_amd.make_params(700, 40, 1, [(350, 20, 0)]), ecoef=CON, slab=(0, 40),
+                        kernel=B.KERNEL_FUSED)
     s.step(30)
     s.comm_init(B.comm_unique_id(), 0, 1)
     s.comm_selftest()
     assert np.array_equal(s.halo_get(0), s.field(B.EZ)[0, 0])
     s.step(5)                      # stepping with a communicator and no neighbours is a no-op exchange
+    # multi-step engine: the packed block of boundary rows (4 rows of 6 arrays + codes) through RCCL
+    m = fdtd_amd.Solver(fdtd_amd.make_params(700, 40, 1, [(350, 3, 0)]), ecoef=CON, slab=(0, 40), kernel=MS4)
+    m.step(30)
+    m.comm_init(B.comm_unique_id(), 0, 1)
+    m.comm_selftest()
+    blk = m.halo_get(0)
+    assert blk.size == 6 * 4 * 700 + 700 and np.array_equal(blk[2 * 4 * 700:2 * 4 * 700 + 700], m.field(B.EZ)[0, 0])
+    assert np.abs(blk).max() > 0
+    m.step(6)
     s3 = fdtd_amd.Solver(fdtd_amd.make_params(40, 30, 20, [(20, 15, 10)]), ecoef=CON)
     s3.step(20)
     s3.comm_init(B.comm_unique_id(), 0, 1)
@@ -232,14 +250,16 @@ def test_rccl_binding_with_a_one_rank_communicator():
 
 
 @pytest.mark.timeout(300)
-def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path):
+@pytest.mark.parametrize("spp", [0, 4])
+def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path, spp):
     """Two ranks (two processes, both on GPU 0) run the slab protocol with the HIP engine
     and gloo-staged halos; the joined result equals the oracle bit for bit."""
     import subprocess
     import sys
-    nx, ny, steps = 1500, 200, 120
+    nx, ny, steps = 1500, 200, 122
     script = os.path.join(os.path.dirname(__file__), "slab_rank_main.py")
-    procs = [subprocess.Popen([sys.executable, script, str(r), "2", "29517", str(nx), str(ny), str(steps), str(tmp_path)])
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2", str(29517 + spp), str(nx), str(ny), str(steps),
+                               str(tmp_path), str(spp)])
              for r in range(2)]
     assert [p.wait(timeout=240) for p in procs] == [0, 0]
     o = oracle.Oracle(oracle.make_params(nx, ny, 1, [(nx // 2, ny // 2, 0), (10, ny // 2 - 1, 0)]), ecoef=CON)
@@ -250,6 +270,28 @@ def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path):
 
 
 # ------------------------------------------------------------------ results path
+
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS4])
+def test_probe_series_of_multi_step_passes(oracle, kernel):
+    """Probes on grid edges, strip edges (x = 247/248) and band edges (y = 31/32) over passes and
+    single steps mixed: every step's row of the ring equals the oracle, bit for bit."""
+    nx, ny = 520, 100
+    s, o = util.pair(oracle, (nx, ny, 1), [(260, 50, 0), (3, 3, 0)], CON, kernel=kernel, sigma=0.3, eps_s=4.0,
+                     eps_i=2.0, tau_d=1e-11)
+    probes = [[260, 50, 0], [0, 40, 0], [519, 41, 0], [100, 0, 0], [101, 99, 0], [247, 31, 0], [248, 32, 0],
+              [4, 4, 0], [1, 1, 0]]
+    s.set_probes(probes, capacity=256)
+    series = []
+    for n in (1, 8, 3, 4, 5, 40, 2, 37):
+        s.step(n)
+        for _ in range(n):
+            o.step(1)
+            series.append([[o.field(f)[0, y, x] for f in (B.HX, B.HY, B.DZ, B.EZ)] for x, y, _ in probes])
+    got = s.read_probes(0, 100)
+    want = np.array(series, dtype=np.float32)
+    assert np.abs(want[:, 1:5, 3]).max() > 0          # the wave reached the boundary probes
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
 
 def test_probes_and_snapshot_agree_with_read_field(oracle):
     s, o = util.pair(oracle, (400, 300, 1), [(200, 150, 0)], CON)
@@ -391,14 +433,15 @@ def test_cli_runs_like_the_reference_and_writes_its_output_format(oracle, tmp_pa
 
 # ------------------------------------------------------------------ checkpoint / restart
 
-@pytest.mark.parametrize("dims", [(300, 200, 1), (40, 30, 20)])
-def test_checkpoint_restart_continues_bit_exactly(oracle, tmp_path, dims):
+@pytest.mark.parametrize("dims,kernel", [((300, 200, 1), B.KERNEL_AUTO), ((40, 30, 20), B.KERNEL_AUTO),
+                                         ((300, 200, 1), MS3)])
+def test_checkpoint_restart_continues_bit_exactly(oracle, tmp_path, dims, kernel):
     src = [(dims[0] // 2, dims[1] // 2, dims[2] // 2)]
     rng = np.random.default_rng(21)
     codes = rng.integers(0, len(util.RIKEN_LIKE), size=dims[::-1], dtype=np.uint8)
 
     def make():
-        s = fdtd_amd.Solver(fdtd_amd.make_params(*dims, src), ecoef=CON)
+        s = fdtd_amd.Solver(fdtd_amd.make_params(*dims, src), ecoef=CON, kernel=kernel)
         for code, row in enumerate(util.RIKEN_LIKE):
             s.set_material(code, *[float(v) for v in row])
         s.set_codes(codes)

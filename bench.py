@@ -4,8 +4,9 @@
 One "step" is one full time step (H, D, source, E, Mur) of one slab.  At
 --gpus 1 the workload is BASELINE.json's configs[1]: a 16384 x 16384 2-D TMz
 grid, vacuum, one point source at the centre.  At --gpus N every rank holds a
-16384 x 16384 slab of a 16384 x (16384*N) grid (weak scaling) and exchanges one
-ez row with each neighbour per step over RCCL.  The metric is
+16384 x 16384 slab of a 16384 x (16384*N) grid (weak scaling) and exchanges halo
+rows with each neighbour over RCCL (once per pass of the multi-step sweep: four
+rows of every array; once per step, one ez row, with the one-step kernels).  The metric is
 Mcell-updates/s = cells * steps / seconds / 1e6, whole job.
 
 Prints one JSON line (rank 0) with the roofline of the dominant kernel (HBM
@@ -23,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BYTES_PER_CELL_2D = 41   # read hx hy ez^n ez^n-1 dz^n dz^n-1 (24) + code (1); write hx hy ez dz (16)
+BYTES_PER_CELL_PASS_2D = 49  # multi-step sweep, per cell and PASS: the same reads (25); write hx hy + two levels of ez, dz (24)
 BYTES_PER_CELL_3D = 97   # read 3 H + 6 E + 6 D (60) + code (1); write 3 H + 3 E + 3 D (36)
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak
 
@@ -48,12 +50,12 @@ def cpu_baseline(nx, ny, budget_s=20.0):
     }
 
 
-def measured_traffic(workload):
+def measured_traffic(workload, kernel, spp):
     """HBM bytes per sweep launch from the committed rocprofv3 PMC passes, if any."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(f"{workload} [{kernel} x{spp}]", {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -165,6 +167,9 @@ def main():
             halo = "host-staged over gloo (RCCL failed to initialise), 1 E row per neighbour per step"
         else:
             halo = "RCCL send/recv, 1 E row per neighbour per step"
+        if solver.steps_per_pass > 1:
+            halo = halo.replace("1 E row per neighbour per step",
+                                f"{solver.steps_per_pass} rows of 6 arrays + codes per neighbour per pass")
 
     src_rank = min(world - 1, src[0][2 if is3d else 1] // (args.nz if is3d else args.ny))
     solver.set_probes([src[0]], capacity=args.steps + args.warmup)
@@ -246,13 +251,21 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(workload),
+                "traffic": measured_traffic(workload, solver.sweep_kernel_name, spp),
                 "kernel": solver.sweep_kernel_name,
                 "kernel_avg_ms": sweep_avg_ms,
                 "algorithmic_bytes_per_cell": bytes_per_cell,
                 "cell_updates_per_launch": cells_per_rank * spp,
+                "steps_per_launch": spp,
             },
         }
+        if spp > 1 and not is3d:
+            # The multi-step sweep moves 49 B per cell and pass instead of 41 B per cell and step,
+            # so `frac` (algorithmic bytes of one-step sweeps / time / peak) can exceed 1; this is
+            # the bandwidth the kernel really draws according to the same byte model.
+            moved = cells_per_rank * BYTES_PER_CELL_PASS_2D / (sweep_avg_ms * 1e-3) / 1e9
+            out["roofline"]["moved_model"] = {"bytes_per_cell_per_launch": BYTES_PER_CELL_PASS_2D,
+                                              "GB/s": moved, "frac_of_peak": moved / HBM_PEAK_GBS}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(4096, 4096) if not is3d else None
         print(json.dumps(out), flush=True)

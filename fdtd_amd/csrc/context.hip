@@ -559,7 +559,7 @@ int pass_once(fdtd_ctx *c)
     for (int s = 0; s < kMaxStepsPerPass; ++s)
         a.slot[s] = (a.ring && s >= 1 && s < K) ? (int)((c->step + s - 1) % c->probe_cap) : 0;
     a.rows = c->tb_rows;
-    a.strips = ((c->nx + 3) / 4 + 61) / 62;
+    a.strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     launch_sweep2d_tb(a, K, c->stream);
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
@@ -654,8 +654,10 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             (void)hipSetDevice(opt->device);
             const size_t rows = (size_t)(opt->slab_count > 0 ? opt->slab_count : p->ny) + 2 * kMaxStepsPerPass;
             const double need = 49.0 * (double)rows * (double)((p->nx + 63) / 64 * 64) * 1.03 + 64e6;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > need &&
-                (opt->slab_count <= 0 || opt->slab_count >= kMaxStepsPerPass))
+            // below a few million cells a pass is bound by the latency of its row-by-row march,
+            // not by bandwidth, and the one-step sweep is as fast or faster (measured crossover: 2048^2)
+            const bool large = (double)p->nx * (double)(rows - 2 * kMaxStepsPerPass) >= 6e6;
+            if (large && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > need)
                 c->kernel = FDTD_KERNEL_MULTISTEP;
         }
     }
@@ -673,6 +675,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             set_error("steps_per_pass must be 2, 3 or 4");
             return -3;
         }
+        c->tb_rows = 0; // chosen once the slab is known
         if (const char *v = std::getenv("FDTD_TB_ROWS")) c->tb_rows = std::max(2, std::atoi(v));
         c->halo = c->tb_steps;
     }
@@ -682,6 +685,13 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     if (c->s0 < 0 || c->sn < 2 || c->s0 + c->sn > c->gn) {
         set_error("slab must hold at least 2 rows inside the grid");
         return -3;
+    }
+    if (c->kernel == FDTD_KERNEL_MULTISTEP && c->tb_rows == 0) {
+        // 32 rows per wave keep the recomputed rows (2K - 1 per wave) cheap; smaller grids trade
+        // that for enough waves to fill the 256 CUs
+        const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
+        c->tb_rows = 32;
+        while (c->tb_rows > 4 && ((c->sn + c->tb_rows - 1) / c->tb_rows) * strips < 4096) c->tb_rows /= 2;
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->sn != c->gn && c->sn < c->tb_steps) {
         set_error("a slab of the multi-step mode must hold at least steps_per_pass rows");

@@ -79,6 +79,8 @@ struct Sweep2D {
 
 // The multi-step 2-D sweep (sweep2d_tb.hip): K time steps in one pass over memory.
 constexpr int kMaxStepsPerPass = 4;
+constexpr int kTbOwnWords = 60; // 16-byte words of a row a wave owns
+constexpr int kTbHaloWords = 2; // words it holds on either side of them
 struct SweepTB {
     Grid2D g;
     const float *hx_r, *hy_r;   // H, read generation (step n - 1/2)
@@ -99,7 +101,7 @@ struct SweepTB {
     float *ring;                          // probe ring, nullptr = no probes
     int slot[kMaxStepsPerPass];           // ring slots of the intermediate levels 1 .. K-1
     int rows;                             // owned rows per wave
-    int strips;                           // waves across a row (62 owned words each)
+    int strips;                           // waves across a row (kTbOwnWords owned words each)
 };
 
 struct Mur2D {

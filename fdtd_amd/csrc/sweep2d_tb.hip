@@ -10,10 +10,12 @@
 // cell) whatever K is.  The arithmetic per cell and step is the same sequence
 // of IEEE operations as in the one-step sweep.
 //
-// Work decomposition.  A wave owns 62 consecutive 16-byte words (248 columns)
-// of `rows` consecutive rows; lane 0 and lane 63 hold the words to the left and
-// right of them, whose level-s values are only valid in their 4 - s columns next
-// to the owned words (one column is lost per step, hence K <= 4).  The wave
+// Work decomposition.  A wave owns 60 consecutive 16-byte words (240 columns,
+// 960 bytes: every wave's stores start on a 64-byte boundary, which HBM writes
+// need -- 62 owned words cost 6 %) of `rows` consecutive rows; lanes 0-1 and
+// 62-63 hold the words to the left and right of them, whose level-s values are
+// only valid in the 8 - s columns next to the owned words (one column is lost
+// per step; K <= 4 is a register budget, not this limit).  The wave
 // marches upwards; in iteration j stage s works on row j - (s - 1), so the
 // pipeline is primed K rows below the first owned row and drained K - 1 rows
 // above the last: rows outside the owned window are recomputed, not
@@ -45,7 +47,7 @@ struct StageOut {
 template <int K, bool ONE>
 __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
 {
-    constexpr int OWN = 62;
+    constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords;
     const Grid2D &g = a.g;
     const int lane = threadIdx.x & 63;
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -53,10 +55,10 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
     const int y0 = (int)(wv / a.strips) * a.rows;
     if (y0 >= g.nyl) return;
     const int y1 = min(y0 + a.rows, g.nyl);
-    const int w = strip * OWN - 1 + lane; // word of the row held by this lane
+    const int w = strip * OWN - LEFT + lane; // word of the row held by this lane
     const int x4 = w * 4;
     const bool act = w >= 0 && x4 < g.nx;
-    const bool own = act && lane >= 1 && lane <= OWN;
+    const bool own = act && lane >= LEFT && lane < LEFT + OWN;
     const long pitch = g.pitch;
 
     bool m_hx[4], m_hy[4], m_ez[4];
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
     }
     // the x = nx-1 Mur cell: word and component, and whether this wave holds it
     const int xe_w = (g.nx - 1) >> 2, xe_c = (g.nx - 1) & 3;
-    const int w_first = strip * OWN - 1;
+    const int w_first = strip * OWN - LEFT;
     const bool wave_xe = xe_w >= w_first && xe_w < w_first + 64;
 
     // sources and probes inside the window of this wave (wave-uniform masks)
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
     if (K > 1 && a.ring) {
         for (int s = 0; s < a.probes.count; ++s) {
             const int js = a.probes.y[s] - g.gy0, ws = a.probes.x[s] >> 2;
-            if (ws > w_first && ws <= w_first + OWN && js >= y0 && js < y1 && a.probes.x[s] >= 0 &&
+            if (ws >= w_first + LEFT && ws < w_first + LEFT + OWN && js >= y0 && js < y1 && a.probes.x[s] >= 0 &&
                 a.probes.x[s] < g.nx)
                 prbmask |= 1u << s;
         }

@@ -1,7 +1,9 @@
 """The N > 1 path on CPUs: world_size-2 and -3 process groups (gloo) run the slab
 protocol of fdtd_amd.slab -- partition_rows, SlabRunner, one ez row per
 neighbour per step, the hx halo row recomputed locally -- with the CPU oracle as
-the per-slab engine, and must reproduce the single-slab oracle bit for bit.
+the per-slab engine, and must reproduce the single-slab oracle bit for bit.  The
+deep-halo form of the protocol (several steps per exchange, what the multi-step
+GPU engine does) is restated with the oracle as well.
 The GPU engine (fdtd_amd.Solver) implements the same three calls; its slab
 tests are in test_parity_gpu.py."""
 import os
@@ -38,13 +40,49 @@ class OracleSlabEngine:
         ez[0 if side == 0 else self.nyl + 1] = rows
 
 
+class OracleDeepSlabEngine:
+    """The deep-halo protocol of the multi-step GPU engine, restated with the oracle: the slab also
+    holds `depth` rows of each neighbour, advances `depth` steps without talking to anybody (the
+    borrowed rows go stale from the outside in, one row per step, and never reach an owned row), and
+    then takes the neighbours' boundary rows of every array -- H, both levels of ez and dz."""
+    ARRAYS = None
+
+    def __init__(self, orc, params, ecoef, slab, depth, codes=None, table=None):
+        b, n = slab
+        self.steps_per_pass = depth
+        self.depth, self.n = depth, n
+        self.lo = min(depth, b)                              # neighbour rows held below / above
+        self.hi = min(depth, params.ny - (b + n))
+        self.o = orc.Oracle(params, ecoef=ecoef, slab=(b - self.lo, n + self.lo + self.hi))
+        if codes is not None:
+            self.o.set_materials(codes[b - self.lo:b + n + self.hi][None], table)
+        self.ARRAYS = [(orc.HX, 0), (orc.HY, 0), (orc.EZ, 0), (orc.EZ, 1), (orc.DZ, 0), (orc.DZ, 1)]
+
+    def step(self, n):
+        self.o.step(n)
+
+    def field(self, fid):
+        return np.array(self.o.field(fid)[0][self.lo:self.lo + self.n])
+
+    def halo_get(self, side):
+        first = self.lo if side == 0 else self.lo + self.n - self.depth       # my first / last `depth` rows
+        return np.stack([self.o.field(f, l)[0][first:first + self.depth] for f, l in self.ARRAYS])
+
+    def halo_put(self, side, rows):
+        have = self.lo if side == 0 else self.hi
+        assert have == self.depth
+        first = 0 if side == 0 else self.lo + self.n
+        for (f, l), block in zip(self.ARRAYS, rows):
+            self.o.field(f, l)[0][first:first + self.depth] = block
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, nx, ny, steps, out_dir):
+def _worker(rank, world, port, nx, ny, steps, out_dir, depth=0):
     import sys
     sys.path.insert(0, ROOT)
     import fdtd_amd.slab as slab
@@ -60,20 +98,26 @@ def _worker(rank, world, port, nx, ny, steps, out_dir):
         srcs = [(nx // 2, ny // 2, 0), (3, ny // world, 0), (nx - 2, ny // world - 1, 0)]
         p = orc.make_params(nx, ny, 1, srcs, sigma=0.05, eps_s=3.0, eps_i=2.0, tau_d=1e-11)
         part = slab.partition_rows(ny, world)[rank]
-        eng = OracleSlabEngine(orc, p, orc.ECOEF_CONSISTENT, part, codes, table)
+        if depth:
+            eng = OracleDeepSlabEngine(orc, p, orc.ECOEF_CONSISTENT, part, depth, codes, table)
+        else:
+            eng = OracleSlabEngine(orc, p, orc.ECOEF_CONSISTENT, part, codes, table)
         runner = slab.SlabRunner(eng, rank, world, transport="host")
         runner.step(steps)
         for fid in (orc.HX, orc.HY, orc.DZ, orc.EZ):
-            np.save(os.path.join(out_dir, f"f{fid}_r{rank}.npy"), np.array(eng.o.field(fid)[0]))
+            got = eng.field(fid) if depth else np.array(eng.o.field(fid)[0])
+            np.save(os.path.join(out_dir, f"f{fid}_r{rank}.npy"), got)
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_slabs_over_gloo_equal_single_slab(oracle, tmp_path, world):
+@pytest.mark.parametrize("world,depth", [(2, 0), (3, 0), (2, 4), (3, 3)])
+def test_slabs_over_gloo_equal_single_slab(oracle, tmp_path, world, depth):
+    """depth 0: one ez row per neighbour per step.  depth K: the multi-step protocol, K rows of
+    every array per neighbour once per K steps (90 steps = passes plus single steps at the end)."""
     nx, ny, steps = 61, 47, 90
-    mp.spawn(_worker, args=(world, _free_port(), nx, ny, steps, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), nx, ny, steps, str(tmp_path), depth), nprocs=world, join=True)
 
     rng = np.random.default_rng(3)
     table = np.array([[0, 1, 1, 0], [0.6, 56.4, 33.1, 3.5e-11], [0.1, 14.2, 7.4, 3.4e-11]], dtype=np.float32)

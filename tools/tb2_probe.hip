@@ -21,24 +21,32 @@ template <bool NT> __device__ inline void st(f4 v, f4 *p) { if (NT) __builtin_no
 __device__ inline f4 shl(f4 v) { f4 r; r.x = v.y; r.y = v.z; r.z = v.w; r.w = __shfl_down(v.x, 1); return r; }
 __device__ inline f4 shr(f4 v) { f4 r; r.y = v.x; r.z = v.y; r.w = v.z; r.x = __shfl_up(v.w, 1); return r; }
 
-template <int R, bool NT> __global__ __launch_bounds__(256) void tb2(Arrays a)
+// ALT: odd bands march downwards (so both neighbours touch the rows they share at the same time);
+// PAD: blocks per row of bands padded to a multiple of 8 (vertical neighbours on one XCD).
+template <int R, bool NT, int K, bool ALT, bool PAD, int OWN, int LEFT> __global__ __launch_bounds__(256) void tb2(Arrays a)
 {
     const int lane = threadIdx.x & 63;
-    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int strip = (int)(wave % a.strips);
-    const long band = wave / a.strips;
+    const int bpr = (a.strips + 3) / 4, bprp = PAD ? (bpr + 7) / 8 * 8 : bpr;
+    const int xb = blockIdx.x % bprp;
+    const long band = blockIdx.x / bprp;
+    if (xb >= bpr) return;
+    const int strip = xb * 4 + (threadIdx.x >> 6);
+    if (strip >= a.strips) return;
     const long y0 = band * R;
     if (y0 >= a.rows) return;
-    int w = strip * 60 - 2 + lane;
+    const bool down = ALT && (band & 1);
+    int w = strip * OWN - LEFT + lane;
     const bool inrow = w >= 0 && w < a.words;
-    const bool own = lane >= 2 && lane < 62 && inrow;
+    const bool own = lane >= LEFT && lane < LEFT + OWN && inrow;
     if (!inrow) w = w < 0 ? 0 : a.words - 1;
     // carried state of the previous row
     f4 hx1p = {0, 0, 0, 0}, hy1p = hx1p, ez1p = hx1p, ez0p = hx1p, dz1p = hx1p, dz0p = hx1p, hx2pp = hx1p;
-    long y = y0 - 1;
+    long y = y0 - K;
     if (y < 0) y = 0;
     f4 ez0 = ld<false>(a.ez0 + y * a.words + w);
-    for (long j = y0 - 1; j <= y0 + R && j < a.rows; ++j) {
+    for (long jj = y0 - K; jj <= y0 + R + K - 2; ++jj) {
+        const long j = down ? (y0 - K) + (y0 + R + K - 2) - jj : jj;
+        if (j >= a.rows) continue;
         const long row = j < 0 ? 0 : j;
         const size_t o = (size_t)row * a.words + w;
         const long up = row + 1 < a.rows ? row + 1 : row;
@@ -55,8 +63,9 @@ template <int R, bool NT> __global__ __launch_bounds__(256) void tb2(Arrays a)
         const f4 hy2 = hy1p + 0.5f * (shl(ez1p) - ez1p);
         const f4 dz2 = dz1p + 0.5f * (hy2 - shr(hy2)) - 0.5f * (hx2 - hx2pp);
         const f4 ez2 = 0.3f * ez1p - 0.2f * ez0p + 0.9f * dz2 - 0.4f * dz1p + 0.1f * dz0p;
-        if (own && j - 1 >= y0 && j - 1 < y0 + R) {
-            const size_t q = (size_t)(j - 1) * a.words + w;
+        const long out = down ? j + 1 : j - 1;
+        if (own && out >= y0 && out < y0 + R && out < a.rows) {
+            const size_t q = (size_t)out * a.words + w;
             st<NT>(hx2, a.hxn + q);
             st<NT>(hy2, a.hyn + q);
             st<NT>(ez1p, a.ez1 + q);
@@ -69,24 +78,24 @@ template <int R, bool NT> __global__ __launch_bounds__(256) void tb2(Arrays a)
     }
 }
 
-template <int R, bool NT> void run(Arrays a)
+template <int R, bool NT, int K, bool ALT, bool PAD, int OWN, int LEFT> void run(Arrays a)
 {
+    a.strips = (a.words + OWN - 1) / OWN;
     const long bands = (a.rows + R - 1) / R;
-    const long waves = bands * a.strips;
-    const unsigned blocks = (unsigned)((waves + 3) / 4);
+    const int bpr = (a.strips + 3) / 4, bprp = PAD ? (bpr + 7) / 8 * 8 : bpr;
+    const unsigned blocks = (unsigned)(bands * bprp);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((tb2<R, NT>), dim3(blocks), dim3(256), 0, 0, a);
+    for (int i = 0; i < 2; ++i) hipLaunchKernelGGL((tb2<R, NT, K, ALT, PAD, OWN, LEFT>), dim3(blocks), dim3(256), 0, 0, a);
     hipEventRecord(e0);
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((tb2<R, NT>), dim3(blocks), dim3(256), 0, 0, a);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((tb2<R, NT, K, ALT, PAD, OWN, LEFT>), dim3(blocks), dim3(256), 0, 0, a);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     ms /= 5;
-    printf("R=%2d nt=%d: %.3f ms per 2-step pass, %.1f Gcell-updates/s\n", R, (int)NT, ms,
-           2.0 * a.words * 4 * a.rows / ms / 1e6);
+    printf("R=%2d nt=%d K=%d own=%d left=%d: %.3f ms per pass\n", R, (int)NT, K, OWN, LEFT, ms);
     fflush(stdout);
 }
 
@@ -106,8 +115,14 @@ int main(int argc, char **argv)
     a.dz0 = (f4 *)buf[8]; a.dzm = (f4 *)buf[9]; a.dz1 = (f4 *)buf[10]; a.dz2 = (f4 *)buf[11];
     a.words = n / 4;
     a.rows = n;
-    a.strips = (a.words + 59) / 60;
-    run<4, true>(a); run<8, true>(a); run<16, true>(a); run<32, true>(a); run<64, true>(a);
-    run<8, false>(a); run<16, false>(a); run<32, false>(a);
+    a.strips = (a.words + 61) / 62;
+    run<32, true, 4, false, false, 62, 1>(a);
+    run<32, true, 4, false, false, 60, 2>(a);
+    run<32, true, 4, false, false, 60, 1>(a);
+    run<32, true, 4, false, false, 56, 4>(a);
+    run<32, true, 4, false, false, 48, 8>(a);
+    run<32, true, 2, false, false, 60, 2>(a);
+    run<64, true, 4, false, false, 60, 2>(a);
+    run<32, false, 4, false, false, 60, 2>(a);
     return 0;
 }

@@ -647,16 +647,16 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     c->ecoef = opt->ecoef;
     c->kernel = opt->kernel;
     if (c->kernel == FDTD_KERNEL_AUTO) {
-        // 2-D: four steps per pass when the 49 bytes per cell it keeps resident fit, else one
+        // 2-D: several steps per pass when the 49 bytes per cell that keeps resident fit, else one
         c->kernel = FDTD_KERNEL_FUSED;
         if (c->is2d()) {
             size_t free_b = 0, total_b = 0;
             (void)hipSetDevice(opt->device);
-            const size_t rows = (size_t)(opt->slab_count > 0 ? opt->slab_count : p->ny) + 2 * kMaxStepsPerPass;
+            const size_t rows = (size_t)(opt->slab_count > 0 ? opt->slab_count : p->ny) + 2 * kDefaultStepsPerPass;
             const double need = 49.0 * (double)rows * (double)((p->nx + 63) / 64 * 64) * 1.03 + 64e6;
             // below a few million cells a pass is bound by the latency of its row-by-row march,
             // not by bandwidth, and the one-step sweep is as fast or faster (measured crossover: 2048^2)
-            const bool large = (double)p->nx * (double)(rows - 2 * kMaxStepsPerPass) >= 6e6;
+            const bool large = (double)p->nx * (double)(rows - 2 * kDefaultStepsPerPass) >= 6e6;
             if (large && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > need)
                 c->kernel = FDTD_KERNEL_MULTISTEP;
         }
@@ -670,9 +670,9 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             set_error("FDTD_KERNEL_MULTISTEP exists for the 2-D TMz mode only");
             return -3;
         }
-        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : kMaxStepsPerPass;
+        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : kDefaultStepsPerPass;
         if (c->tb_steps < 2 || c->tb_steps > kMaxStepsPerPass) {
-            set_error("steps_per_pass must be 2, 3 or 4");
+            set_error("steps_per_pass must be 2 .. 6");
             return -3;
         }
         c->tb_rows = 0; // chosen once the slab is known
@@ -687,10 +687,10 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         return -3;
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->tb_rows == 0) {
-        // 32 rows per wave keep the recomputed rows (2K - 1 per wave) cheap; smaller grids trade
+        // 32 to 64 rows per wave keep the recomputed rows (2K - 1 per wave) cheap; smaller grids trade
         // that for enough waves to fill the 256 CUs
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
-        c->tb_rows = 32;
+        c->tb_rows = c->tb_steps >= 5 ? 64 : 32;
         while (c->tb_rows > 4 && ((c->sn + c->tb_rows - 1) / c->tb_rows) * strips < 4096) c->tb_rows /= 2;
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->sn != c->gn && c->sn < c->tb_steps) {

@@ -15,7 +15,7 @@
 // need -- 62 owned words cost 6 %) of `rows` consecutive rows; lanes 0-1 and
 // 62-63 hold the words to the left and right of them, whose level-s values are
 // only valid in the 8 - s columns next to the owned words (one column is lost
-// per step; K <= 4 is a register budget, not this limit).  The wave
+// per step; the register budget, not this, limits K: 5 stages fit two waves per SIMD).  The wave
 // marches upwards; in iteration j stage s works on row j - (s - 1), so the
 // pipeline is primed K rows below the first owned row and drained K - 1 rows
 // above the last: rows outside the owned window are recomputed, not
@@ -292,6 +292,8 @@ void launch_sweep2d_tb(const SweepTB &a, int steps, void *stream)
     case 2: launch_k<2>(a, (hipStream_t)stream); break;
     case 3: launch_k<3>(a, (hipStream_t)stream); break;
     case 4: launch_k<4>(a, (hipStream_t)stream); break;
+    case 5: launch_k<5>(a, (hipStream_t)stream); break;
+    case 6: launch_k<6>(a, (hipStream_t)stream); break;
     default: launch_k<1>(a, (hipStream_t)stream); break;
     }
 }

@@ -79,8 +79,8 @@ def test_3d_mur_from_loaded_materials(oracle):
 
 # ------------------------------------------------------------------ 2-D TMz
 
-MS2, MS3, MS4 = (B.KERNEL_MULTISTEP, 2), (B.KERNEL_MULTISTEP, 3), (B.KERNEL_MULTISTEP, 4)
-KERNELS = [B.KERNEL_FUSED, B.KERNEL_SPLIT, MS2, MS3, MS4]
+MS2, MS3, MS4, MS5, MS6 = [(B.KERNEL_MULTISTEP, k) for k in (2, 3, 4, 5, 6)]
+KERNELS = [B.KERNEL_FUSED, B.KERNEL_SPLIT, MS2, MS3, MS4, MS5, MS6]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -250,7 +250,7 @@ def test_rccl_binding_with_a_one_rank_communicator():
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("spp", [0, 4])
+@pytest.mark.parametrize("spp", [0, 5])
 def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path, spp):
     """Two ranks (two processes, both on GPU 0) run the slab protocol with the HIP engine
     and gloo-staged halos; the joined result equals the oracle bit for bit."""
@@ -271,7 +271,7 @@ def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path, spp):
 
 # ------------------------------------------------------------------ results path
 
-@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS4])
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS5])
 def test_probe_series_of_multi_step_passes(oracle, kernel):
     """Probes on grid edges, strip edges (x = 247/248) and band edges (y = 31/32) over passes and
     single steps mixed: every step's row of the ring equals the oracle, bit for bit."""

@@ -12,6 +12,6 @@ def run(nx, ny, kernel, pgm=0, steps=120, src=None):
     t0 = time.perf_counter(); s.step(steps); s.sync(); el = time.perf_counter() - t0
     print(f"{nx}x{ny} pgm={pgm} kernel={kernel} {s.sweep_kernel_name}: {el/steps*1e3:.4f} ms/step {nx*ny*steps/el/1e9:.1f} Gcell/s", flush=True)
     s.close()
-for k in (B.KERNEL_FUSED, (B.KERNEL_MULTISTEP, 2), (B.KERNEL_MULTISTEP, 4)):
+for k in (B.KERNEL_FUSED, (B.KERNEL_MULTISTEP, 4), (B.KERNEL_MULTISTEP, 5)):
     run(8480, 15680, k, pgm=32)
     run(265, 490, k, pgm=1, steps=1200, src=(40, 245, 0))

@@ -210,13 +210,15 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
         r.cd = act ? *(const unsigned *)(a.code + off) : 0u;
     };
 
-    Level c[K + 1]; // c[s]: level s-1 of the row stage s works on next (c[1] comes from memory)
-    f4 hxb[K + 1];  // hxb[s]: level-s hx of the row below it
+    // c[s]: level s-1 of the row stage s works on next (c[1] comes from memory).  While stage s
+    // works on row r, c[s + 1] still holds level s of row r - 1: its hx is the hx below that the
+    // D update of stage s needs; the last stage keeps that row's hx in hx_top.
+    Level c[K + 1];
+    f4 hx_top = zero;
 #pragma unroll
     for (int s = 0; s <= K; ++s) {
         c[s].ez = c[s].hx = c[s].hy = c[s].dz = c[s].ezp = c[s].dzp = zero;
         c[s].cd = 0;
-        hxb[s] = zero;
     }
 
     RowIn cur;
@@ -225,8 +227,6 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
 
     for (int j = jlo; j <= jhi; ++j) {
         RowIn nxt;
-        if (j < jhi) load(nxt, j + 1);
-
         c[1].ez = ezc;
         c[1].hx = cur.hx;
         c[1].hy = cur.hy;
@@ -239,7 +239,9 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
 #pragma unroll
         for (int s = 1; s <= K; ++s) {
             const int r = j - (s - 1);
-            StageOut o = stage(c[s], ezu, hxb[s], r, a.jz[s - 1]);
+            StageOut o = stage(c[s], ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r, a.jz[s - 1]);
+            // the next row's loads go out once stage 1 has consumed this row's registers
+            if (s == 1 && j < jhi) load(nxt, j + 1);
             if (s < K) {
                 const int y = g.gy0 + r;
                 mur_x(o.ez, c[s].ez, r);
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
                 st4_stream(a.dz_a + q, c[K].dz);
                 st4_stream(a.ez_a + q, c[K].ez);
             }
-            hxb[s] = o.hx;
+            if (s == K) hx_top = o.hx;
             ezu = o.ez;
         }
 #pragma unroll

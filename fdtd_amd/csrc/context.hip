@@ -2,12 +2,14 @@
 // the per-step schedule, field/probe/snapshot transfers.
 //
 // Storage.  Every field is its own padded array in HBM (SoA): rows of `pitch`
-// floats (a multiple of 64, so every row starts on a 256-byte line), one halo
-// row (2-D, y axis) or halo plane (3-D, z axis) on either side of the slab.
+// floats (2-D: a multiple of 64, so every row starts on a 256-byte line; fused
+// 3-D sweep: a multiple of 16), one halo row (2-D, y axis) or halo plane (3-D,
+// z axis) on either side of the slab -- K halo rows in the multi-step 2-D mode.
 // E and D keep two time levels: level n+1 is written over level n-1 once the
 // cell's E update has consumed it (the reference rotates three buffers,
 // fdtd.cu:206-211; cells it never writes are zero in all three, so two levels
-// give the same values).  Materials are one byte per cell plus a table of at
+// give the same values).  The multi-step mode holds two such pairs of arrays
+// and writes the two newest levels of a pass into the pair it did not read.  Materials are one byte per cell plus a table of at
 // most 256 coefficient rows instead of four floats per cell.
 #include <hip/hip_runtime.h>
 

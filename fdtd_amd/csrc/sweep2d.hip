@@ -5,11 +5,11 @@
 // Work decomposition.  A wave owns 256 consecutive columns of one row (lane l
 // holds columns 4l..4l+3, one 16-byte word per array) and `chunk_rows` rows,
 // one after the other; a workgroup is four such waves side by side.  Blocks are
-// numbered x first, so at any moment the blocks in flight cover a compact band
-// of rows of every array -- the access pattern of a flat copy, which is what
-// HBM (and the TLBs) serve fastest; with chunk_rows = 1 the band is as narrow
-// as it can be.  The number of x blocks is padded to a multiple of 8 so that
-// vertically adjacent blocks land on the same XCD and share its L2.
+// numbered so that at any moment the blocks in flight cover a compact band of
+// rows of every array -- the access pattern of a flat copy, which is what HBM
+// (and the TLBs) serve fastest; with chunk_rows = 1 the band is as narrow as it
+// can be.  Inside a band of 32 rows the hardware's round-robin of block ids
+// over the 8 XCDs is undone, so that vertically adjacent blocks share an L2.
 //
 // Neighbours.  dz^{n+1}(x, y) needs the NEW hy at x-1 and the NEW hx at y-1.
 // x: from the adjacent lane (shuffle); the lane at the left edge of the strip

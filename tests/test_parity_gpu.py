@@ -179,6 +179,9 @@ def test_2d_slabs_equal_whole_grid(oracle, kernel, world):
             slabs[r + 1].halo_put(0, up)
             slabs[r].halo_put(1, down)
 
+    probes = [(150, 50, 0), (10, 0, 0), (299, 100, 0), (151, parts[1][0], 0), (152, parts[1][0] - 1, 0)]
+    for sv in [whole] + slabs:
+        sv.set_probes(probes, capacity=160)
     stride, done, steps = whole.steps_per_pass, 0, 150
     exchange()                              # the deep halos also carry the neighbours' material codes
     while done < steps:
@@ -193,6 +196,15 @@ def test_2d_slabs_equal_whole_grid(oracle, kernel, world):
         got = np.concatenate([sv.field(fid) for sv in slabs], axis=1)
         assert np.array_equal(full.view(np.uint32), got.view(np.uint32)), B.FIELD_NAMES[fid]
     assert np.abs(whole.field(B.EZ)).max() > 0
+    # a probe is recorded by the slab that holds it and reads as zero on the others
+    series = whole.read_probes(0, steps)
+    parts_series = [sv.read_probes(0, steps) for sv in slabs]
+    assert np.array_equal(sum(parts_series).view(np.uint32), (series + np.float32(0)).view(np.uint32))
+    assert np.abs(series[:, 3:]).max() > 0
+    for k, (x, y, _) in enumerate(probes):
+        for (b, n), got in zip(parts, parts_series):
+            if not b <= y < b + n:
+                assert not got[:, k].any()
 
 
 @pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, B.KERNEL_SPLIT])

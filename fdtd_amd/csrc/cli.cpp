@@ -15,6 +15,9 @@
 //   --upsample U         repeat each PGM pixel U x U times
 //   --no-materials       keep the fsigma/feps_s/feps_inf/ftau_d defaults everywhere
 //   --output-every N     write fields every N steps (default 1, 0 = never)
+//   --axis-lines         also write E_field_{x,y,z}_%05d.out: all nine fields along the three
+//                        grid lines through every source (writeResults, fdtd.cu:1197-1285)
+//   --no-planes          with --axis-lines: skip the per-plane files
 //   --device N
 #include <algorithm>
 #include <chrono>
@@ -83,13 +86,60 @@ static void write_field(const fdtd_params &p, const char *family, char axis, int
     }
 }
 
+// writeResults (fdtd.cu:1197-1285): for every source the x, y and z grid lines through it, one text
+// line per cell: 1-based indices, then D, H, E (x y z each).  Read as windows, not whole fields.
+static void write_axis_lines(fdtd_ctx *ctx, const fdtd_params &p, bool is2d, int iteration)
+{
+    static const int order[9] = {FDTD_DX, FDTD_DY, FDTD_DZ, FDTD_HX, FDTD_HY, FDTD_HZ, FDTD_EX, FDTD_EY, FDTD_EZ};
+    const int extent[3] = {p.nx, p.ny, p.nz};
+    for (int axis = 0; axis < 3; axis++) {
+        char path[2304];
+        std::snprintf(path, sizeof path, "%s/E_field_%c_%05d.out", p.output_path, "xyz"[axis], iteration + 1);
+        FILE *f = std::fopen(path, "w");
+        if (!f) {
+            std::printf("Couldn't open file %s\n", path);
+            std::exit(EXIT_FAILURE);
+        }
+        const int n = extent[axis];
+        std::vector<float> line((size_t)9 * n);
+        for (int isrc = 0; isrc < p.sources_count; isrc++) {
+            const int sx = p.sources[isrc * 3], sy = p.sources[isrc * 3 + 1], sz = is2d ? 0 : p.sources[isrc * 3 + 2];
+            for (int k = 0; k < 9; k++) {
+                float *dst = &line[(size_t)k * n];
+                const int field = order[k];
+                const bool held = !is2d || field == FDTD_HX || field == FDTD_HY || field == FDTD_DZ || field == FDTD_EZ;
+                if (!held) {
+                    std::fill(dst, dst + n, 0.0f);
+                    continue;
+                }
+                int rc = 0;
+                if (axis == 0)
+                    rc = fdtd_read_window(ctx, field, 0, (int64_t)sz * p.ny + sy, 1, 0, p.nx, dst);
+                else if (axis == 1)
+                    rc = fdtd_read_window(ctx, field, 0, (int64_t)sz * p.ny, p.ny, sx, 1, dst);
+                else
+                    for (int iz = 0; iz < p.nz && !rc; iz++)
+                        rc = fdtd_read_window(ctx, field, 0, (int64_t)iz * p.ny + sy, 1, sx, 1, dst + iz);
+                if (rc) die("reading a grid line");
+            }
+            for (int i = 0; i < n; i++) {
+                const int ix = axis == 0 ? i : sx, iy = axis == 1 ? i : sy, iz = axis == 2 ? i : sz;
+                std::fprintf(f, " %3d %3d %3d", ix + 1, iy + 1, iz + 1);
+                for (int k = 0; k < 9; k++) std::fprintf(f, " % 9.3E", line[(size_t)k * n + i]);
+                std::fprintf(f, "\n");
+            }
+        }
+        std::fclose(f);
+    }
+}
+
 int main(int argc, char **argv)
 {
     std::string params_path = "data/input_params", specs_path = "data/mat_specs_riken";
     fdtd_options opt;
     fdtd_options_default(&opt);
     int first_slice = 1, upsample = 1, output_every = 1;
-    bool materials = true;
+    bool materials = true, axis_lines = false, planes = true;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         auto value = [&]() -> const char * {
@@ -109,6 +159,8 @@ int main(int argc, char **argv)
         else if (a == "--no-materials") materials = false;
         else if (a == "--output-every") output_every = std::atoi(value());
         else if (a == "--device") opt.device = std::atoi(value());
+        else if (a == "--axis-lines") axis_lines = true;
+        else if (a == "--no-planes") planes = false;
         else {
             std::printf("Error: unknown argument %s\n", a.c_str());
             return EXIT_FAILURE;
@@ -146,7 +198,8 @@ int main(int argc, char **argv)
         first = i + 1;
         if (output_every > 0 && i % output_every == 0) {
             std::printf("Writing results for iteration %d\n", i + 1);
-            for (int fam = 0; fam < 3; fam++)
+            if (axis_lines) write_axis_lines(ctx, p, is2d, i);
+            for (int fam = 0; planes && fam < 3; fam++)
                 for (int k = 0; k < 3; k++) {
                     const int field = fam * 3 + k;
                     const bool held = !is2d || field == FDTD_HX || field == FDTD_HY || field == FDTD_DZ || field == FDTD_EZ;

@@ -467,6 +467,25 @@ def test_cli_runs_like_the_reference_and_writes_its_output_format(oracle, tmp_pa
                     got = (tmp_path / "output" / f"{fam}_field_{axis}_{it:05d}_z{iz:05d}.out").read_text()
                     want = "".join("".join(" % 9.3E" % v for v in row) + "\n" for row in o.field(fid)[iz])
                     assert got == want, (fam, axis, it, iz)
+    # the grid lines through the source (writeResults, fdtd.cu:1197-1285), every second iteration
+    run = subprocess.run([exe, "--axis-lines", "--no-planes", "--output-every", "2"], cwd=tmp_path,
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    o = oracle.Oracle(oracle.load_params(str(data / "input_params")), ecoef=REF)
+    o.load_materials(str(data / "mat_specs_riken"), str(data / "pgmdata"))
+    sx, sy, sz = 10, 8, 2
+    order = (B.DX, B.DY, B.DZ, B.HX, B.HY, B.HZ, B.EX, B.EY, B.EZ)
+    for it in range(3):
+        o.step(1)
+        if it % 2:
+            assert not (tmp_path / "output" / f"E_field_x_{it + 1:05d}.out").exists()
+            continue
+        for axis, n in zip("xyz", (nx, ny, nz)):
+            want = ""
+            for i in range(n):
+                x, y, z = (i if axis == "x" else sx), (i if axis == "y" else sy), (i if axis == "z" else sz)
+                want += " %3d %3d %3d" % (x + 1, y + 1, z + 1) + "".join(" % 9.3E" % o.field(f)[z, y, x] for f in order) + "\n"
+            assert (tmp_path / "output" / f"E_field_{axis}_{it + 1:05d}.out").read_text() == want, (axis, it)
     # a missing parameter file is reported and fails the process, it does not crash
     bad = subprocess.run([exe, "--params", "data/none"], cwd=tmp_path, capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "Error" in bad.stdout

@@ -561,6 +561,14 @@ int pass_once(fdtd_ctx *c)
     for (int s = 0; s < kMaxStepsPerPass; ++s)
         a.slot[s] = (a.ring && s >= 1 && s < K) ? (int)((c->step + s - 1) % c->probe_cap) : 0;
     a.rows = c->tb_rows;
+    {
+        // the last sixteenth of the slab (at most 1024 rows) goes in bands a quarter as high
+        int tail = std::min(1024, c->sn / 16), short_rows = std::max(4, c->tb_rows / 4);
+        if (const char *v = std::getenv("FDTD_TB_TAIL")) tail = std::atoi(v);
+        if (tail + c->tb_rows > c->sn || short_rows >= c->tb_rows) tail = 0;
+        a.tail_rows = tail > 0 ? short_rows : c->tb_rows;
+        a.big_bands = tail > 0 ? (c->sn - tail) / c->tb_rows : (c->sn + c->tb_rows - 1) / c->tb_rows;
+    }
     a.strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     launch_sweep2d_tb(a, K, c->stream);

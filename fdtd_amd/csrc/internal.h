@@ -102,6 +102,7 @@ struct SweepTB {
     float *ring;                          // probe ring, nullptr = no probes
     int slot[kMaxStepsPerPass];           // ring slots of the intermediate levels 1 .. K-1
     int rows;                             // owned rows per wave
+    int big_bands, tail_rows;             // bands of `rows` rows; the rows after them go in bands of tail_rows
     int strips;                           // waves across a row (kTbOwnWords owned words each)
 };
 

@@ -52,9 +52,13 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
     const int lane = threadIdx.x & 63;
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int strip = (int)(wv % a.strips);
-    const int y0 = (int)(wv / a.strips) * a.rows;
+    // The first big_bands bands hold `rows` rows each, the bands after them tail_rows: short waves
+    // at the end of the launch keep the GPU full while the last long ones finish (3 % at 16384^2).
+    const int band = (int)(wv / a.strips);
+    const bool big = band < a.big_bands;
+    const int y0 = big ? band * a.rows : a.big_bands * a.rows + (band - a.big_bands) * a.tail_rows;
     if (y0 >= g.nyl) return;
-    const int y1 = min(y0 + a.rows, g.nyl);
+    const int y1 = min(y0 + (big ? a.rows : a.tail_rows), g.nyl);
     const int w = strip * OWN - LEFT + lane; // word of the row held by this lane
     const int x4 = w * 4;
     const bool act = w >= 0 && x4 < g.nx;
@@ -277,7 +281,8 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
 
 template <int K> void launch_k(const SweepTB &a, hipStream_t stream)
 {
-    const long bands = (a.g.nyl + a.rows - 1) / a.rows;
+    const long done = (long)a.big_bands * a.rows;
+    const long bands = a.big_bands + (done < a.g.nyl ? (a.g.nyl - done + a.tail_rows - 1) / a.tail_rows : 0);
     const long waves = bands * a.strips;
     const dim3 grid((unsigned)((waves + 3) / 4));
     if (a.ntab == 1)

@@ -521,11 +521,10 @@ void record_probes(fdtd_ctx *c, int mid)
     }
 }
 
-// MULTISTEP: tb_steps time steps in one pass (sweep2d_tb.hip), then Mur on the newest level.
-int pass_once(fdtd_ctx *c)
+// MULTISTEP: K <= tb_steps time steps in one pass (sweep2d_tb.hip), then Mur on the newest level.
+int pass_once(fdtd_ctx *c, int K)
 {
     const bool prof = c->prof_n < c->prof_cap;
-    const int K = c->tb_steps;
     SweepTB a;
     a.g = grid2d(c);
     a.hx_r = c->h[0][c->hgen];
@@ -682,7 +681,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         }
         c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : kDefaultStepsPerPass;
         if (c->tb_steps < 2 || c->tb_steps > kMaxStepsPerPass) {
-            set_error("steps_per_pass must be 2 .. 6");
+            set_error("steps_per_pass must be 2 .. 8");
             return -3;
         }
         c->tb_rows = 0; // chosen once the slab is known
@@ -938,10 +937,11 @@ int fdtd_step(fdtd_ctx *c, int nsteps)
         if (rc) return rc;
     }
     for (int i = 0; i < nsteps;) {
-        const bool pass = c->kernel == FDTD_KERNEL_MULTISTEP && nsteps - i >= c->tb_steps;
-        int rc = pass ? pass_once(c) : step_once(c);
+        // full passes, then one shorter pass for the remainder (a single step: the one-step sweep)
+        const int k = c->kernel == FDTD_KERNEL_MULTISTEP ? std::min(nsteps - i, c->tb_steps) : 1;
+        int rc = k >= 2 ? pass_once(c, k) : step_once(c);
         if (rc) return rc;
-        i += pass ? c->tb_steps : 1;
+        i += k;
     }
     return 0;
 }

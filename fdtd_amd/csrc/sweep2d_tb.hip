@@ -27,25 +27,28 @@
 // right after the E update of the row, the y = 0 row one iteration later (it
 // needs the new row 1), the y = ny-1 row from the carried row ny-2.  Level K is
 // stored as the E update leaves it; the ordinary Mur kernel finishes it.
+#include <type_traits>
+
 #include "device_math.h"
 
 namespace fdtd {
 
 namespace {
 
-// Level s-1 of one row: what stage s consumes.
+// Level s-1 of one row: what stage s consumes and a wave carries in registers from one iteration
+// to the next.  The E update also needs ez and dz of level s-2; those only wait, so they wait in LDS.
 struct Level {
-    f4 ez, hx, hy, dz; // level s-1
-    f4 ezp, dzp;       // level s-2
-    unsigned cd;       // four material codes
+    f4 ez, hx, hy, dz;
+    unsigned cd; // four material codes
 };
 
 struct StageOut {
     f4 ez, hx, hy, dz;
 };
 
+// At least two waves per SIMD (the register allocator otherwise settles for one at some K).
 template <int K, bool ONE>
-__global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
+__global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
 {
     constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords;
     const Grid2D &g = a.g;
@@ -96,8 +99,18 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
 
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    // One stage: level s-1 of row r (and ez of row r + 1, hx of level s of row r - 1) -> level s of row r.
-    auto stage = [&](const Level &in, const f4 &ezu, const f4 &hxb, int r, float jz) -> StageOut {
+    // LDS: per wave and stage s >= 2 one slot {ez, dz} of level s-2 for the row stage s works on next;
+    // every lane reads and writes its own 16 bytes, no other wave touches them: no barriers.
+    __shared__ f4 parked[4][K > 1 ? K - 1 : 1][2][64];
+    f4(*park)[2][64] = parked[threadIdx.x >> 6];
+
+    // One stage: level s-1 of row r (with ez, dz of level s-2, ez of row r + 1, hx of level s of
+    // row r - 1) -> level s of row r.
+    // `inner` (a compile-time flag): the wave and all its rows lie inside the guards of every
+    // update, away from the Mur faces, sources and probes -- the guards fold away.
+    auto stage = [&](auto inner, const Level &in, const f4 &ezp, const f4 &dzp, const f4 &ezu, const f4 &hxb, int r,
+                     float jz) -> StageOut {
+        constexpr bool IN = decltype(inner)::value;
         const int y = g.gy0 + r;
         const bool gy_hx = y >= 0 && y <= g.gny - 2;
         const bool gy_in = y >= 1 && y <= g.gny - 2;
@@ -107,14 +120,14 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
         const float er[4] = {in.ez.y, in.ez.z, in.ez.w, e_right};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            o.hx[i] = (gy_hx && m_hx[i]) ? in.hx[i] - g.kh_y * (ezu[i] - in.ez[i]) : in.hx[i];
-            o.hy[i] = (gy_in && m_hy[i]) ? in.hy[i] + g.kh_x * (er[i] - in.ez[i]) : in.hy[i];
+            o.hx[i] = (IN || (gy_hx && m_hx[i])) ? in.hx[i] - g.kh_y * (ezu[i] - in.ez[i]) : in.hx[i];
+            o.hy[i] = (IN || (gy_in && m_hy[i])) ? in.hy[i] + g.kh_x * (er[i] - in.ez[i]) : in.hy[i];
         }
         const float hy_left = __shfl_up(o.hy.w, 1);
         const float hl[4] = {hy_left, o.hy.x, o.hy.y, o.hy.z};
 
         unsigned srcflag = 0;
-        if (srcmask) {
+        if (!IN && srcmask) {
             for (int s = 0; s < a.src.count; ++s) {
                 if (!((srcmask >> s) & 1u) || a.src.y[s] - g.gy0 != r) continue;
                 if ((a.src.x[s] >> 2) == w) srcflag |= 1u << (a.src.x[s] & 3);
@@ -123,8 +136,8 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = (in.dz[i] + g.cx * (o.hy[i] - hl[i])) - g.cy * (o.hx[i] - hxb[i]);
-            float dn = (gy_in && m_hx[i]) ? v : in.dzp[i];
-            if ((srcflag >> i) & 1u) dn = v - jz;
+            float dn = (IN || (gy_in && m_hx[i])) ? v : dzp[i];
+            if (!IN && ((srcflag >> i) & 1u)) dn = v - jz;
             o.dz[i] = dn;
         }
 
@@ -138,14 +151,14 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
         if (uniform) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                o.ez[i] = (gy_ez && m_ez[i]) ? e_update(mu, g.dt, in.ez[i], in.ezp[i], o.dz[i], in.dz[i], in.dzp[i])
-                                             : in.ezp[i];
+                o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(mu, g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                                                     : ezp[i];
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const MatEntry m = a.table[(in.cd >> (8 * i)) & 0xffu];
-                o.ez[i] = (gy_ez && m_ez[i]) ? e_update(m, g.dt, in.ez[i], in.ezp[i], o.dz[i], in.dz[i], in.dzp[i])
-                                             : in.ezp[i];
+                o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m, g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                                                     : ezp[i];
             }
         }
         return o;
@@ -203,17 +216,20 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
         f4 hx, hy, ezp, dz, dzp, ezu;
         unsigned cd;
     };
-    auto load = [&](RowIn &r, int j) {
+    auto load = [&](auto inner, RowIn &r, int j) {
+        const bool ld = decltype(inner)::value || act;
         const long off = (long)(j + 1) * pitch + x4;
-        r.hx = act ? ld4_stream(a.hx_r + off) : zero;
-        r.hy = act ? ld4_stream(a.hy_r + off) : zero;
-        r.ezp = act ? ld4_stream(a.ez_p + off) : zero;
-        r.dz = act ? ld4_stream(a.dz_n + off) : zero;
-        r.dzp = act ? ld4_stream(a.dz_p + off) : zero;
-        r.ezu = act ? ld4_stream(a.ez_n + off + pitch) : zero;
-        r.cd = act ? *(const unsigned *)(a.code + off) : 0u;
+        r.hx = ld ? ld4_stream(a.hx_r + off) : zero;
+        r.hy = ld ? ld4_stream(a.hy_r + off) : zero;
+        r.ezp = ld ? ld4_stream(a.ez_p + off) : zero;
+        r.dz = ld ? ld4_stream(a.dz_n + off) : zero;
+        r.dzp = ld ? ld4_stream(a.dz_p + off) : zero;
+        r.ezu = ld ? ld4_stream(a.ez_n + off + pitch) : zero;
+        r.cd = ld ? *(const unsigned *)(a.code + off) : 0u;
     };
 
+    auto march = [&](auto inner) {
+    constexpr bool IN = decltype(inner)::value;
     // c[s]: level s-1 of the row stage s works on next (c[1] comes from memory).  While stage s
     // works on row r, c[s + 1] still holds level s of row r - 1: its hx is the hx below that the
     // D update of stage s needs; the last stage keeps that row's hx in hx_top.
@@ -221,13 +237,12 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
     f4 hx_top = zero;
 #pragma unroll
     for (int s = 0; s <= K; ++s) {
-        c[s].ez = c[s].hx = c[s].hy = c[s].dz = c[s].ezp = c[s].dzp = zero;
+        c[s].ez = c[s].hx = c[s].hy = c[s].dz = zero;
         c[s].cd = 0;
     }
-
     RowIn cur;
-    load(cur, jlo);
-    f4 ezc = act ? ld4_stream(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
+    load(inner, cur, jlo);
+    f4 ezc = (IN || act) ? ld4_stream(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
 
     for (int j = jlo; j <= jhi; ++j) {
         RowIn nxt;
@@ -235,31 +250,49 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
         c[1].hx = cur.hx;
         c[1].hy = cur.hy;
         c[1].dz = cur.dz;
-        c[1].ezp = cur.ezp;
-        c[1].dzp = cur.dzp;
         c[1].cd = cur.cd;
         f4 ezu = cur.ezu;
+        // ez, dz of level s-1 of the row stage s has just done: the level s-2 values stage s+1 needs
+        // for that row in the next iteration.  They go into its slot once it has taken out this
+        // iteration's pair.
+        f4 pend_e = zero, pend_d = zero;
         Level keep[K + 1];
 #pragma unroll
         for (int s = 1; s <= K; ++s) {
             const int r = j - (s - 1);
-            StageOut o = stage(c[s], ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r, a.jz[s - 1]);
+            f4 ezp, dzp;
+            if (s == 1) {
+                ezp = cur.ezp;
+                dzp = cur.dzp;
+            } else {
+                ezp = park[s - 2][0][lane];
+                dzp = park[s - 2][1][lane];
+                park[s - 2][0][lane] = pend_e;
+                park[s - 2][1][lane] = pend_d;
+            }
+            StageOut o = stage(inner, c[s], ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r, a.jz[s - 1]);
             // the next row's loads go out once stage 1 has consumed this row's registers
-            if (s == 1 && j < jhi) load(nxt, j + 1);
+            if (s == 1 && j < jhi) load(inner, nxt, j + 1);
             if (s < K) {
                 const int y = g.gy0 + r;
-                mur_x(o.ez, c[s].ez, r);
-                if (y == g.gny - 1) mur_y(o.ez, c[s + 1].ez, c[s + 1].ezp, c[s].ez, a.rpye, true);
-                if (y == 1) mur_y(c[s + 1].ez, o.ez, c[s].ez, c[s + 1].ezp, a.rpy0, false);
+                if (!IN) mur_x(o.ez, c[s].ez, r);
+                if (!IN && (y == g.gny - 1 || y == 1)) {
+                    // ez of level s-1 of row r - 1 is parked in the slot of stage s + 1
+                    const f4 below = park[s - 1][0][lane];
+                    if (y == 1)
+                        mur_y(c[s + 1].ez, o.ez, c[s].ez, below, a.rpy0, false);
+                    else
+                        mur_y(o.ez, c[s + 1].ez, below, c[s].ez, a.rpye, true);
+                }
                 // c[s + 1] now holds the final level s of row r - 1
-                if (prbmask && own && r - 1 >= y0 && r - 1 < y1) record(c[s + 1], r - 1, a.slot[s]);
+                if (!IN && prbmask && own && r - 1 >= y0 && r - 1 < y1) record(c[s + 1], r - 1, a.slot[s]);
                 keep[s + 1].ez = o.ez;
                 keep[s + 1].hx = o.hx;
                 keep[s + 1].hy = o.hy;
                 keep[s + 1].dz = o.dz;
-                keep[s + 1].ezp = c[s].ez;
-                keep[s + 1].dzp = c[s].dz;
                 keep[s + 1].cd = c[s].cd;
+                pend_e = c[s].ez;
+                pend_d = c[s].dz;
             } else if (own && r >= y0 && r < y1) {
                 const long q = (long)(r + 1) * pitch + x4;
                 st4_stream(a.hx_w + q, o.hx);
@@ -271,12 +304,24 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep_tb(const SweepTB a)
             }
             if (s == K) hx_top = o.hx;
             ezu = o.ez;
+            // keep the scheduler from interleaving the stages: that only lengthens live ranges
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int s = 2; s <= K; ++s) c[s] = keep[s];
         ezc = cur.ezu;
         cur = nxt;
     }
+    };
+
+    // Inner wave: every lane holds cells 1 .. nx-2 only, every row any stage touches (down to
+    // jlo - (K - 1), whose values are never used) lies in 2 .. ny-3, no source, no probe.
+    const bool inner_wave = w_first >= 1 && (w_first + 63) * 4 + 3 <= g.nx - 2 && g.gy0 + jlo - (K - 1) >= 2 &&
+                            g.gy0 + jhi + 1 <= g.gny - 3 && srcmask == 0 && prbmask == 0;
+    if (inner_wave)
+        march(std::true_type{});
+    else
+        march(std::false_type{});
 }
 
 template <int K> void launch_k(const SweepTB &a, hipStream_t stream)
@@ -301,6 +346,8 @@ void launch_sweep2d_tb(const SweepTB &a, int steps, void *stream)
     case 4: launch_k<4>(a, (hipStream_t)stream); break;
     case 5: launch_k<5>(a, (hipStream_t)stream); break;
     case 6: launch_k<6>(a, (hipStream_t)stream); break;
+    case 7: launch_k<7>(a, (hipStream_t)stream); break;
+    case 8: launch_k<8>(a, (hipStream_t)stream); break;
     default: launch_k<1>(a, (hipStream_t)stream); break;
     }
 }

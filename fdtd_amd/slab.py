@@ -75,7 +75,7 @@ class SlabRunner:
             self.primed = True
         done = 0
         while done < nsteps:
-            n = self.stride if nsteps - done >= self.stride else 1
+            n = min(self.stride, nsteps - done)
             self.engine.step(n)
             self.exchange()
             done += n

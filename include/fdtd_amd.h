@@ -56,7 +56,7 @@ enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
  * MULTISTEP (2-D TMz only): one sweep over memory per `steps_per_pass` steps;
  * the same arithmetic per cell and step, 16 more bytes of HBM per cell (E and D
  * keep four arrays instead of two).  fdtd_step(n) runs n / steps_per_pass
- * passes and the remainder as single steps.
+ * passes and the remainder as one shorter pass (a single step: FUSED).
  * AUTO: MULTISTEP in 2-D when its arrays fit into the free device memory,
  * else FUSED. */
 enum { FDTD_KERNEL_AUTO = 0, FDTD_KERNEL_SPLIT = 1, FDTD_KERNEL_FUSED = 2, FDTD_KERNEL_MULTISTEP = 3 };
@@ -69,7 +69,7 @@ typedef struct fdtd_options {
     int32_t slab_begin;  /* first global row of the slab axis held here (y in 2-D, z in 3-D) */
     int32_t slab_count;  /* rows held; 0 = the whole grid */
     int32_t chunk_rows;  /* rows marched by one workgroup of the fused sweep; 0 = default */
-    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 6; 0 = default (5) */
+    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (6) */
     int32_t reserved[8];
 } fdtd_options;
 

@@ -48,7 +48,7 @@ struct StageOut {
 
 // At least two waves per SIMD (the register allocator otherwise settles for one at some K).
 template <int K, bool ONE>
-__global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
+__global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const SweepTB a)
 {
     constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords;
     const Grid2D &g = a.g;

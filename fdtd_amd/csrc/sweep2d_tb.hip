@@ -15,13 +15,19 @@
 // need -- 62 owned words cost 6 %) of `rows` consecutive rows; lanes 0-1 and
 // 62-63 hold the words to the left and right of them, whose level-s values are
 // only valid in the 8 - s columns next to the owned words (one column is lost
-// per step; the register budget, not this, limits K: 5 stages fit two waves per SIMD).  The wave
+// per step, hence K <= 8; registers limit the useful K to 6 or 7).  The wave
 // marches upwards; in iteration j stage s works on row j - (s - 1), so the
 // pipeline is primed K rows below the first owned row and drained K - 1 rows
 // above the last: rows outside the owned window are recomputed, not
 // communicated.  Because neighbouring waves re-read the rows a wave writes, the
 // output levels live in arrays of their own (no in-place update), and H has a
 // read and a write generation.
+//
+// State.  Between iterations a wave keeps, per stage, ez, hx, hy, dz of the
+// level below in registers; ez and dz two levels below, which the E update
+// reads once, wait in LDS (one slot per lane: no barriers).  Waves whose cells
+// all lie inside every guard and away from faces, sources and probes take a
+// copy of the loop in which the guards are folded away at compile time.
 //
 // Mur.  Levels 1 .. K-1 get their boundary values in registers: the x faces
 // right after the E update of the row, the y = 0 row one iteration later (it
@@ -46,7 +52,8 @@ struct StageOut {
     f4 ez, hx, hy, dz;
 };
 
-// At least two waves per SIMD (the register allocator otherwise settles for one at some K).
+// At least two waves per SIMD up to K = 7 (the register allocator otherwise settles for one at
+// some K); K = 8 would spill at two and runs at one.
 template <int K, bool ONE>
 __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const SweepTB a)
 {

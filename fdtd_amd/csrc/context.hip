@@ -699,8 +699,10 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         // 32 to 64 rows per wave keep the recomputed rows (2K - 1 per wave) cheap; smaller grids trade
         // that for enough waves to fill the 256 CUs
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
+        // (measured at K = 6: 16384^2 64 rows, 8192^2 32, 4096^2 and 3072^2 16)
         c->tb_rows = c->tb_steps >= 5 ? 64 : 32;
-        while (c->tb_rows > 4 && ((c->sn + c->tb_rows - 1) / c->tb_rows) * strips < 4096) c->tb_rows /= 2;
+        const int least = (double)c->nx * c->sn >= 6e6 ? 16 : 4;
+        while (c->tb_rows > least && ((c->sn + c->tb_rows - 1) / c->tb_rows) * strips < 8192) c->tb_rows /= 2;
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->sn != c->gn && c->sn < c->tb_steps) {
         set_error("a slab of the multi-step mode must hold at least steps_per_pass rows");

@@ -153,6 +153,39 @@ def test_2d_upsampled_pgm_matches_oracle_on_repeated_codes(oracle):
     assert util.run_and_compare(s, o, 300, 100, "upsampled PGM") == 0
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_2d_multi_step_random_cases(oracle, seed):
+    """Seeded random cases of the multi-step sweep: grid size (strip and band edges included),
+    steps per pass, sources (also on the last column and row), tissue maps, rp planes, state and
+    the way the steps are cut into calls -- every field bit for bit after every call."""
+    rng = np.random.default_rng(1000 + seed)
+    nx = int(rng.choice([3, 4, 5, 239, 240, 241, 244, 480, 481, int(rng.integers(6, 700))]))
+    ny = int(rng.choice([3, 4, 5, 16, 17, 63, 64, 65, int(rng.integers(6, 200))]))
+    k = int(rng.integers(2, 9))
+    nsrc = int(rng.integers(1, 5))
+    srcs = [(int(rng.integers(1, nx)), int(rng.integers(1, ny)), 0) for _ in range(nsrc)]
+    s, o = util.pair(oracle, (nx, ny, 1), srcs, CON, kernel=(B.KERNEL_MULTISTEP, k), sigma=0.2, eps_s=9.0, eps_i=3.0,
+                     tau_d=2e-11)
+    if rng.random() < 0.7:
+        codes = rng.integers(0, len(util.RIKEN_LIKE), size=(1, ny, nx), dtype=np.uint8)
+        if rng.random() < 0.5:
+            codes[:, :, : nx // 2] = codes[0, 0, 0]          # uniform waves next to mixed ones
+        util.set_materials(s, o, codes)
+    for face in (0, 1, 3, 4):
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    if rng.random() < 0.5:
+        util.randomize(s, o, rng, oracle)
+    peak = util.Peak()
+    for n in rng.integers(1, 3 * k + 2, size=5):
+        for _ in range(int(n)):
+            o.step(1)
+            peak.update(o, util.fields_of(s))
+        s.step(int(n))
+        assert util.compare(s, o, peak, f"seed {seed} nx {nx} ny {ny} K {k}") == 0
+
+
 # ------------------------------------------------------------------ slabs
 
 @pytest.mark.parametrize("kernel", KERNELS)

@@ -23,9 +23,9 @@
 // output levels live in arrays of their own (no in-place update), and H has a
 // read and a write generation.
 //
-// State.  Between iterations a wave keeps, per stage, ez, hx, hy, dz of the
-// level below in registers; ez and dz two levels below, which the E update
-// reads once, wait in LDS (one slot per lane: no barriers).  Waves whose cells
+// State.  Between iterations a wave keeps, per stage, ez, hx, dz of the level
+// below in registers; what is read exactly once -- hy of that level, ez and dz
+// two levels below -- waits in LDS (one slot per lane: no barriers).  Waves whose cells
 // all lie inside every guard and away from faces, sources and probes take a
 // copy of the loop in which the guards are folded away at compile time.
 //
@@ -42,9 +42,10 @@ namespace fdtd {
 namespace {
 
 // Level s-1 of one row: what stage s consumes and a wave carries in registers from one iteration
-// to the next.  The E update also needs ez and dz of level s-2; those only wait, so they wait in LDS.
+// to the next.  Stage s also needs hy of level s-1 and ez, dz of level s-2, each read exactly once:
+// those wait in LDS.
 struct Level {
-    f4 ez, hx, hy, dz;
+    f4 ez, hx, dz;
     unsigned cd; // four material codes
 };
 
@@ -106,17 +107,18 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
 
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
 
-    // LDS: per wave and stage s >= 2 one slot {ez, dz} of level s-2 for the row stage s works on next;
-    // every lane reads and writes its own 16 bytes, no other wave touches them: no barriers.
-    __shared__ f4 parked[4][K > 1 ? K - 1 : 1][2][64];
-    f4(*park)[2][64] = parked[threadIdx.x >> 6];
+    // LDS: per wave and stage s >= 2 one slot {ez, dz of level s-2, hy of level s-1} for the row
+    // stage s works on next; every lane reads and writes its own 16 bytes, no other wave touches
+    // them: no barriers.
+    __shared__ f4 parked[4][K > 1 ? K - 1 : 1][3][64];
+    f4(*park)[3][64] = parked[threadIdx.x >> 6];
 
     // One stage: level s-1 of row r (with ez, dz of level s-2, ez of row r + 1, hx of level s of
     // row r - 1) -> level s of row r.
     // `inner` (a compile-time flag): the wave and all its rows lie inside the guards of every
     // update, away from the Mur faces, sources and probes -- the guards fold away.
-    auto stage = [&](auto inner, const Level &in, const f4 &ezp, const f4 &dzp, const f4 &ezu, const f4 &hxb, int r,
-                     float jz) -> StageOut {
+    auto stage = [&](auto inner, const Level &in, const f4 &hyin, const f4 &ezp, const f4 &dzp, const f4 &ezu,
+                     const f4 &hxb, int r, float jz) -> StageOut {
         constexpr bool IN = decltype(inner)::value;
         const int y = g.gy0 + r;
         const bool gy_hx = y >= 0 && y <= g.gny - 2;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             o.hx[i] = (IN || (gy_hx && m_hx[i])) ? in.hx[i] - g.kh_y * (ezu[i] - in.ez[i]) : in.hx[i];
-            o.hy[i] = (IN || (gy_in && m_hy[i])) ? in.hy[i] + g.kh_x * (er[i] - in.ez[i]) : in.hy[i];
+            o.hy[i] = (IN || (gy_in && m_hy[i])) ? hyin[i] + g.kh_x * (er[i] - in.ez[i]) : hyin[i];
         }
         const float hy_left = __shfl_up(o.hy.w, 1);
         const float hl[4] = {hy_left, o.hy.x, o.hy.y, o.hy.z};
@@ -202,15 +204,15 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
         }
     };
 
-    auto record = [&](const Level &v, int r, int slot) {
+    auto record = [&](const Level &v, const f4 &vhy, int r, int slot) {
         for (int s = 0; s < a.probes.count; ++s) {
             if (!((prbmask >> s) & 1u) || a.probes.y[s] - g.gy0 != r || (a.probes.x[s] >> 2) != w) continue;
             const int i = a.probes.x[s] & 3;
             float *dst = a.ring + ((size_t)slot * FDTD_MAX_PROBES + s) * 4;
-            float hx = v.hx.x, hy = v.hy.x, dz = v.dz.x, ez = v.ez.x;
+            float hx = v.hx.x, hy = vhy.x, dz = v.dz.x, ez = v.ez.x;
 #pragma unroll
             for (int q = 1; q < 4; ++q)
-                if (q == i) hx = v.hx[q], hy = v.hy[q], dz = v.dz[q], ez = v.ez[q];
+                if (q == i) hx = v.hx[q], hy = vhy[q], dz = v.dz[q], ez = v.ez[q];
             dst[0] = hx;
             dst[1] = hy;
             dst[2] = dz;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
     f4 hx_top = zero;
 #pragma unroll
     for (int s = 0; s <= K; ++s) {
-        c[s].ez = c[s].hx = c[s].hy = c[s].dz = zero;
+        c[s].ez = c[s].hx = c[s].dz = zero;
         c[s].cd = 0;
     }
     RowIn cur;
@@ -255,29 +257,32 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
         RowIn nxt;
         c[1].ez = ezc;
         c[1].hx = cur.hx;
-        c[1].hy = cur.hy;
         c[1].dz = cur.dz;
         c[1].cd = cur.cd;
         f4 ezu = cur.ezu;
-        // ez, dz of level s-1 of the row stage s has just done: the level s-2 values stage s+1 needs
+        // ez, dz of level s-1 and the new hy of the row stage s has just done: what stage s+1 needs
         // for that row in the next iteration.  They go into its slot once it has taken out this
-        // iteration's pair.
-        f4 pend_e = zero, pend_d = zero;
+        // iteration's values.
+        f4 pend_e = zero, pend_d = zero, pend_h = zero;
         Level keep[K + 1];
 #pragma unroll
         for (int s = 1; s <= K; ++s) {
             const int r = j - (s - 1);
-            f4 ezp, dzp;
+            f4 ezp, dzp, hyin;
             if (s == 1) {
                 ezp = cur.ezp;
                 dzp = cur.dzp;
+                hyin = cur.hy;
             } else {
                 ezp = park[s - 2][0][lane];
                 dzp = park[s - 2][1][lane];
+                hyin = park[s - 2][2][lane];
                 park[s - 2][0][lane] = pend_e;
                 park[s - 2][1][lane] = pend_d;
+                park[s - 2][2][lane] = pend_h;
             }
-            StageOut o = stage(inner, c[s], ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r, a.jz[s - 1]);
+            StageOut o = stage(inner, c[s], hyin, ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r,
+                               a.jz[s - 1]);
             // the next row's loads go out once stage 1 has consumed this row's registers
             if (s == 1 && j < jhi) load(inner, nxt, j + 1);
             if (s < K) {
@@ -292,14 +297,15 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
                         mur_y(o.ez, c[s + 1].ez, below, c[s].ez, a.rpye, true);
                 }
                 // c[s + 1] now holds the final level s of row r - 1
-                if (!IN && prbmask && own && r - 1 >= y0 && r - 1 < y1) record(c[s + 1], r - 1, a.slot[s]);
+                if (!IN && prbmask && own && r - 1 >= y0 && r - 1 < y1)
+                    record(c[s + 1], park[s - 1][2][lane], r - 1, a.slot[s]);
                 keep[s + 1].ez = o.ez;
                 keep[s + 1].hx = o.hx;
-                keep[s + 1].hy = o.hy;
                 keep[s + 1].dz = o.dz;
                 keep[s + 1].cd = c[s].cd;
                 pend_e = c[s].ez;
                 pend_d = c[s].dz;
+                pend_h = o.hy;
             } else if (own && r >= y0 && r < y1) {
                 const long q = (long)(r + 1) * pitch + x4;
                 st4_stream(a.hx_w + q, o.hx);

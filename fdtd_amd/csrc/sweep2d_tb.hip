@@ -56,7 +56,7 @@ struct StageOut {
 // At least two waves per SIMD up to K = 7 (the register allocator otherwise settles for one at
 // some K); K = 8 would spill at two and runs at one.
 template <int K, bool ONE>
-__global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const SweepTB a)
+__global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
 {
     constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords;
     const Grid2D &g = a.g;
@@ -110,8 +110,12 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
     // LDS: per wave and stage s >= 2 one slot {ez, dz of level s-2, hy of level s-1} for the row
     // stage s works on next; every lane reads and writes its own 16 bytes, no other wave touches
     // them: no barriers.
-    __shared__ f4 parked[4][K > 1 ? K - 1 : 1][3][64];
-    f4(*park)[3][64] = parked[threadIdx.x >> 6];
+    // (K = 8: 21 slots per wave would leave room for one block per CU only; the hy of its last
+    // stage stays in registers instead.)
+    constexpr bool HY_LAST_IN_REGS = K >= 8;
+    __shared__ f4 parked[4][K > 1 ? 3 * (K - 1) - (HY_LAST_IN_REGS ? 1 : 0) : 1][64];
+    f4(*park_w)[64] = parked[threadIdx.x >> 6];
+    auto park = [&](int stage_index, int which) -> f4 & { return park_w[3 * stage_index + which][lane]; };
 
     // One stage: level s-1 of row r (with ez, dz of level s-2, ez of row r + 1, hx of level s of
     // row r - 1) -> level s of row r.
@@ -244,6 +248,7 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
     // D update of stage s needs; the last stage keeps that row's hx in hx_top.
     Level c[K + 1];
     f4 hx_top = zero;
+    f4 hy_last = zero, hy_last_new = zero; // HY_LAST_IN_REGS: hy of level K-1 for stage K, this and the next iteration
 #pragma unroll
     for (int s = 0; s <= K; ++s) {
         c[s].ez = c[s].hx = c[s].dz = zero;
@@ -274,12 +279,17 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
                 dzp = cur.dzp;
                 hyin = cur.hy;
             } else {
-                ezp = park[s - 2][0][lane];
-                dzp = park[s - 2][1][lane];
-                hyin = park[s - 2][2][lane];
-                park[s - 2][0][lane] = pend_e;
-                park[s - 2][1][lane] = pend_d;
-                park[s - 2][2][lane] = pend_h;
+                ezp = park(s - 2, 0);
+                dzp = park(s - 2, 1);
+                park(s - 2, 0) = pend_e;
+                park(s - 2, 1) = pend_d;
+                if (HY_LAST_IN_REGS && s == K) {
+                    hyin = hy_last;
+                    hy_last_new = pend_h;
+                } else {
+                    hyin = park(s - 2, 2);
+                    park(s - 2, 2) = pend_h;
+                }
             }
             StageOut o = stage(inner, c[s], hyin, ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r,
                                a.jz[s - 1]);
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
                 if (!IN) mur_x(o.ez, c[s].ez, r);
                 if (!IN && (y == g.gny - 1 || y == 1)) {
                     // ez of level s-1 of row r - 1 is parked in the slot of stage s + 1
-                    const f4 below = park[s - 1][0][lane];
+                    const f4 below = park(s - 1, 0);
                     if (y == 1)
                         mur_y(c[s + 1].ez, o.ez, c[s].ez, below, a.rpy0, false);
                     else
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
                 }
                 // c[s + 1] now holds the final level s of row r - 1
                 if (!IN && prbmask && own && r - 1 >= y0 && r - 1 < y1)
-                    record(c[s + 1], park[s - 1][2][lane], r - 1, a.slot[s]);
+                    record(c[s + 1], (HY_LAST_IN_REGS && s + 1 == K) ? hy_last : park(s - 1, 2), r - 1, a.slot[s]);
                 keep[s + 1].ez = o.ez;
                 keep[s + 1].hx = o.hx;
                 keep[s + 1].dz = o.dz;
@@ -322,6 +332,7 @@ __global__ __launch_bounds__(256, K >= 8 ? 1 : 2) void fdtd2d_sweep_tb(const Swe
         }
 #pragma unroll
         for (int s = 2; s <= K; ++s) c[s] = keep[s];
+        hy_last = hy_last_new;
         ezc = cur.ezu;
         cur = nxt;
     }

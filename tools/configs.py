@@ -18,3 +18,6 @@ def run(nx, ny, kernel, pgm=0, steps=168, src=None):
 kernels = [B.KERNEL_FUSED] + [(B.KERNEL_MULTISTEP, k) for k in (int(v) for v in (sys.argv[1:] or ["4", "5", "6", "7"]))]
 for k in kernels:
     run(8480, 15680, k, pgm=32, steps=840)
+print("same grid, vacuum:")
+for k in kernels[1:]:
+    run(8480, 15680, k, pgm=0, steps=840)

@@ -940,7 +940,8 @@ int fdtd_step(fdtd_ctx *c, int nsteps)
     }
     for (int i = 0; i < nsteps;) {
         // full passes, then one shorter pass for the remainder (a single step: the one-step sweep)
-        const int k = c->kernel == FDTD_KERNEL_MULTISTEP ? std::min(nsteps - i, c->tb_steps) : 1;
+        // (with several materials on the grid a pass advances at most kMaxStepsPerPassTable steps)
+        const int k = std::min(nsteps - i, fdtd_steps_per_pass(c));
         int rc = k >= 2 ? pass_once(c, k) : step_once(c);
         if (rc) return rc;
         i += k;
@@ -948,7 +949,11 @@ int fdtd_step(fdtd_ctx *c, int nsteps)
     return 0;
 }
 
-int fdtd_steps_per_pass(const fdtd_ctx *c) { return c->kernel == FDTD_KERNEL_MULTISTEP ? c->tb_steps : 1; }
+int fdtd_steps_per_pass(const fdtd_ctx *c)
+{
+    if (c->kernel != FDTD_KERNEL_MULTISTEP) return 1;
+    return c->ntab > 1 ? std::min(c->tb_steps, kMaxStepsPerPassTable) : c->tb_steps;
+}
 
 int fdtd_sync(fdtd_ctx *c)
 {

@@ -59,6 +59,13 @@ template <int K, bool ONE>
 __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
 {
     constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords;
+    // Grids with several materials: the coefficient table (256 rows of 16 bytes) sits in LDS, where a
+    // lookup per cell and stage costs a fraction of a cached global load.
+    __shared__ MatEntry tab[ONE ? 1 : FDTD_MAX_CODES];
+    if (!ONE) {
+        tab[threadIdx.x] = a.table[threadIdx.x];
+        __syncthreads(); // before any wave leaves
+    }
     const Grid2D &g = a.g;
     const int lane = threadIdx.x & 63;
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
         if (!ONE) {
             const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)in.cd) & 0xffu;
             uniform = __all(in.cd == c0 * 0x01010101u);
-            if (uniform) mu = a.table[c0];
+            if (uniform) mu = tab[c0];
         }
         if (uniform) {
 #pragma unroll
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const MatEntry m = a.table[(in.cd >> (8 * i)) & 0xffu];
+                const MatEntry m = tab[(in.cd >> (8 * i)) & 0xffu];
                 o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m, g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
                                                      : ezp[i];
             }
@@ -356,7 +363,7 @@ template <int K> void launch_k(const SweepTB &a, hipStream_t stream)
     const dim3 grid((unsigned)((waves + 3) / 4));
     if (a.ntab == 1)
         hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true>), grid, dim3(256), 0, stream, a);
-    else
+    else if constexpr (K <= kMaxStepsPerPassTable)
         hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false>), grid, dim3(256), 0, stream, a);
 }
 

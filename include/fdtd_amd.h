@@ -69,7 +69,7 @@ typedef struct fdtd_options {
     int32_t slab_begin;  /* first global row of the slab axis held here (y in 2-D, z in 3-D) */
     int32_t slab_count;  /* rows held; 0 = the whole grid */
     int32_t chunk_rows;  /* rows marched by one workgroup of the fused sweep; 0 = default */
-    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (6) */
+    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (8; 7 at most once several materials are on the grid) */
     int32_t reserved[8];
 } fdtd_options;
 

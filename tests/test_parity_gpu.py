@@ -438,19 +438,20 @@ def test_2d_largest_grid_65536_window_and_causality(oracle):
 def test_2d_tissue_map_8480x15680_whole_field(oracle):
     """The dispersive workload at its full size: v1_00800.pgm upsampled x32 (8480 x 15680, 133 M
     cells, 8 tissues), mat_specs_riken, Mur with the default rp, a source in the air beside the
-    body.  32 steps (5 passes of 6 + one of 2) against the oracle on the whole grid: every
+    body.  32 steps (4 passes of 7 + one of 4) against the oracle on the whole grid: every
     cell of every field bit for bit."""
     u, steps = 32, 32
     nx, ny = 265 * u, 490 * u
     src = [(40 * u, 245 * u, 0)]
     s = fdtd_amd.Solver(fdtd_amd.make_params(nx, ny, 1, src), ecoef=CON)
-    assert s.steps_per_pass == 6
     o = oracle.Oracle(oracle.make_params(nx, ny, 1, src), ecoef=CON)
     specs, pgm = os.path.join(DATA, "mat_specs_riken"), os.path.join(DATA, "pgmdata")
+    assert s.steps_per_pass == 8
     s.load_materials(specs, pgm, first_slice=800, upsample=u)
     table, _ = B.read_material_specs(specs)
     codes = B.read_pgm_codes(os.path.join(pgm, "v1_00800.pgm"), 265, 490)
     o.set_materials(np.repeat(np.repeat(codes, u, axis=0), u, axis=1)[None], table)
+    assert s.steps_per_pass == 7          # 8 in vacuum; the material table takes part of the LDS
     s.step(steps)
     o.step(steps, threads=16)
     for fid in (B.HX, B.HY, B.DZ, B.EZ):

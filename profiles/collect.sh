@@ -6,7 +6,7 @@
 set -u
 tag=${1:-r01}
 shift || true
-args=${*:---steps 48 --warmup 6 --no-cpu-baseline}
+args=${*:---steps 48 --warmup 8 --no-cpu-baseline}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/$tag
 mkdir -p "$out"

@@ -80,7 +80,7 @@ struct Sweep2D {
 // The multi-step 2-D sweep (sweep2d_tb.hip): K time steps in one pass over memory.
 constexpr int kMaxStepsPerPass = 8;     // one column of the two halo words on either side goes stale per step
 constexpr int kMaxStepsPerPassTable = 7; // grids with several materials: the table takes 4 KB of the LDS
-constexpr int kDefaultStepsPerPass = 8; // 16384^2 vacuum: 5: 430, 6: 499, 7: 496-508, 8: 296 (spills) Gcell-updates/s
+constexpr int kDefaultStepsPerPass = 8; // 16384^2 vacuum: 4: 358, 5: 430, 6: 498, 7: 562, 8: 612 Gcell-updates/s
 constexpr int kTbOwnWords = 60; // 16-byte words of a row a wave owns
 constexpr int kTbHaloWords = 2; // words it holds on either side of them
 struct SweepTB {

@@ -15,7 +15,7 @@
 // need -- 62 owned words cost 6 %) of `rows` consecutive rows; lanes 0-1 and
 // 62-63 hold the words to the left and right of them, whose level-s values are
 // only valid in the 8 - s columns next to the owned words (one column is lost
-// per step, hence K <= 8; registers limit the useful K to 6 or 7).  The wave
+// per step, hence K <= 8; registers and LDS are full at K = 8 too).  The wave
 // marches upwards; in iteration j stage s works on row j - (s - 1), so the
 // pipeline is primed K rows below the first owned row and drained K - 1 rows
 // above the last: rows outside the owned window are recomputed, not
@@ -53,8 +53,7 @@ struct StageOut {
     f4 ez, hx, hy, dz;
 };
 
-// At least two waves per SIMD up to K = 7 (the register allocator otherwise settles for one at
-// some K); K = 8 would spill at two and runs at one.
+// At least two waves per SIMD (the register allocator otherwise settles for one at some K).
 template <int K, bool ONE>
 __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
 {

@@ -75,6 +75,22 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
     const float *ex = a.e_n[0], *ey = a.e_n[1], *ez = a.e_n[2];
     const float *hx = a.h_r[0], *hy = a.h_r[1], *hz = a.h_r[2];
 
+    // Material codes first, and the table rows they select right behind them: a chain of two
+    // dependent loads that would otherwise start only after the 31 field loads have come back.
+    const unsigned cd = act ? *(const unsigned *)(a.code + o) : 0u;
+    bool uniform = true;
+    MatEntry mu = a.one, mm[4];
+    if (!ONE) {
+        const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cd) & 0xffu;
+        uniform = __all(cd == c0 * 0x01010101u);
+        if (uniform) {
+            mu = a.table[c0];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) mm[i] = a.table[(cd >> (8 * i)) & 0xffu];
+        }
+    }
+
     // E^n and old H: own row and the rows below in y and z (and the two diagonals)
     const f4 ex_c = ld4(ex + o, act, false), ex_py = ld4(ex + o + rs, act, false), ex_pz = ld4(ex + o + ps, act, false);
     const f4 ex_my = ld4(ex + o - rs, act, false), ex_mz = ld4(ex + o - ps, act, true);
@@ -92,7 +108,6 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
         d1[c] = ld4(a.d_w[c] + o, act, true);
         e1[c] = ld4(a.e_w[c] + o, act, true);
     }
-    const unsigned cd = act ? *(const unsigned *)(a.code + o) : 0u;
 
     // scalars the lanes at the two ends of the wave lack
     const bool edge_r = (lane == 63) && act && (x4 + 4 < g.nx);
@@ -185,17 +200,10 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
 
     // E, fdtd_calculations.cu:147-182
     f4 en[3];
-    bool uniform = true;
-    MatEntry mu = a.one;
-    if (!ONE) {
-        const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cd) & 0xffu;
-        uniform = __all(cd == c0 * 0x01010101u);
-        if (uniform) mu = a.table[c0];
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         MatEntry m = mu;
-        if (!ONE && !uniform) m = a.table[(cd >> (8 * i)) & 0xffu];
+        if (!ONE && !uniform) m = mm[i];
         const bool g_ex = x_hi[i] && y_lo && y_hi && z_lo && z_hi;
         const bool g_eyz = x_lo[i] && z_lo;
         en[0][i] = g_ex ? e_update(m, g.dt, ex_c[i], e1[0][i], dn[0][i], d0[0][i], d1[0][i]) : e1[0][i];

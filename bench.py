@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="GPU ordinal (default: LOCAL_RANK)")
     ap.add_argument("--snapshot-every", type=int, default=0,
                     help="take an ez snapshot (side-stream D2H) every N steps inside the timed region")
+    ap.add_argument("--probes", type=int, default=1, help="probes recorded every step (1..16), spread over the grid")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --ny (or --nz) is the extent of the WHOLE grid, cut into --gpus slabs")
     args = ap.parse_args()
 
     import numpy as np
@@ -119,6 +122,13 @@ def main():
 
     is3d = args.nz > 1
     nx = args.nx
+    if args.strong:
+        if (args.nz if is3d else args.ny) % world:
+            raise SystemExit("--strong needs the slab axis to be a multiple of --gpus")
+        if is3d:
+            args.nz //= world
+        else:
+            args.ny //= world
     if is3d:
         gdims = (nx, args.ny, args.nz * world)
         slab = (rank * args.nz, args.nz)
@@ -172,7 +182,10 @@ def main():
                                 f"{solver.steps_per_pass} rows of 6 arrays + codes per neighbour per pass")
 
     src_rank = min(world - 1, src[0][2 if is3d else 1] // (args.nz if is3d else args.ny))
-    solver.set_probes([src[0]], capacity=args.steps + args.warmup)
+    # probe 0 sits on the source (it feeds the sanity check below), the others lie on the diagonal
+    nprobes = max(1, min(16, args.probes))
+    probes = [src[0]] + [tuple(int(d * (i + 0.5) / nprobes) if d > 1 else 0 for d in gdims) for i in range(1, nprobes)]
+    solver.set_probes(probes, capacity=args.steps + args.warmup)
 
     def barrier():
         if dist is not None:
@@ -229,7 +242,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -241,9 +254,9 @@ def main():
                 "steps_per_pass": spp,
                 "parallelism": f"slab{world}" if world > 1 else "single",
                 "halo": halo,
-                "output": (f"{snapshots} ez snapshots per rank (async D2H on a side stream) + 1 probe x "
+                "output": (f"{snapshots} ez snapshots per rank (async D2H on a side stream) + {nprobes} probes x "
                            f"{solver.lib.fdtd_probe_fields(solver._ctx)} fields every step") if snapshots
-                else "1 probe every step",
+                else f"{nprobes} probe(s) every step",
             },
             "roofline": {
                 "bound": "hbm",

@@ -564,6 +564,7 @@ int pass_once(fdtd_ctx *c, int K)
         // the last sixteenth of the slab (at most 1024 rows) goes in bands a quarter as high
         int tail = std::min(1024, c->sn / 16), short_rows = std::max(4, c->tb_rows / 4);
         if (const char *v = std::getenv("FDTD_TB_TAIL")) tail = std::atoi(v);
+        if (const char *v = std::getenv("FDTD_TB_TAIL_ROWS")) short_rows = std::max(2, std::atoi(v));
         if (tail + c->tb_rows > c->sn || short_rows >= c->tb_rows) tail = 0;
         a.tail_rows = tail > 0 ? short_rows : c->tb_rows;
         a.big_bands = tail > 0 ? (c->sn - tail) / c->tb_rows : (c->sn + c->tb_rows - 1) / c->tb_rows;

@@ -279,6 +279,9 @@ def main():
             moved = cells_per_rank * BYTES_PER_CELL_PASS_2D / (sweep_avg_ms * 1e-3) / 1e9
             out["roofline"]["moved_model"] = {"bytes_per_cell_per_launch": BYTES_PER_CELL_PASS_2D,
                                               "GB/s": moved, "frac_of_peak": moved / HBM_PEAK_GBS}
+            out["roofline"]["note"] = (f"one launch advances {spp} time steps: `achieved` counts the 41 B per "
+                                       "cell-update a one-step sweep must move, the kernel itself moves 49 B per "
+                                       "cell and launch (moved_model; `traffic` is the PMC measurement)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(4096, 4096) if not is3d else None
         print(json.dumps(out), flush=True)

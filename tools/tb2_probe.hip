@@ -101,28 +101,28 @@ template <int R, bool NT, int K, bool ALT, bool PAD, int OWN, int LEFT> void run
 
 int main(int argc, char **argv)
 {
-    const int n = argc > 1 ? atoi(argv[1]) : 16384;
-    const size_t cells = (size_t)n * n;
+    const int n = argc > 1 ? atoi(argv[1]) : 16384;      // columns
+    const int nrows = argc > 2 ? atoi(argv[2]) : n;
+    const size_t cells = (size_t)n * nrows;
+    // one arena for all arrays: array k starts k * (array bytes rounded up to `quantum`, plus `pad`) into it
+    const size_t pad = argc > 3 ? (size_t)atol(argv[3]) : 4096;
+    const size_t quantum = argc > 4 ? (size_t)atol(argv[4]) : 256;
+    const size_t stride = (cells * 4 + quantum - 1) / quantum * quantum + pad;
+    char *arena;
+    hipMalloc((void **)&arena, 12 * stride + 4096);
+    hipMemset(arena, 0, 12 * stride + 4096);
     float *buf[12];
-    for (auto &b : buf) {
-        hipMalloc((void **)&b, cells * 4 + 4096);
-        hipMemset(b, 0, cells * 4 + 4096);
-    }
+    for (int k = 0; k < 12; ++k) buf[k] = (float *)(arena + k * stride);
+    printf("stride %zu bytes (pad %zu)\n", stride, pad);
     Arrays a;
     a.hx = (f4 *)buf[0]; a.hxn = (f4 *)buf[1];
     a.hy = (f4 *)buf[2]; a.hyn = (f4 *)buf[3];
     a.ez0 = (f4 *)buf[4]; a.ezm = (f4 *)buf[5]; a.ez1 = (f4 *)buf[6]; a.ez2 = (f4 *)buf[7];
     a.dz0 = (f4 *)buf[8]; a.dzm = (f4 *)buf[9]; a.dz1 = (f4 *)buf[10]; a.dz2 = (f4 *)buf[11];
     a.words = n / 4;
-    a.rows = n;
+    a.rows = nrows;
     a.strips = (a.words + 61) / 62;
-    run<32, true, 4, false, false, 62, 1>(a);
+    run<64, true, 8, false, false, 60, 2>(a);
     run<32, true, 4, false, false, 60, 2>(a);
-    run<32, true, 4, false, false, 60, 1>(a);
-    run<32, true, 4, false, false, 56, 4>(a);
-    run<32, true, 4, false, false, 48, 8>(a);
-    run<32, true, 2, false, false, 60, 2>(a);
-    run<64, true, 4, false, false, 60, 2>(a);
-    run<32, false, 4, false, false, 60, 2>(a);
     return 0;
 }

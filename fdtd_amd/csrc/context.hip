@@ -561,8 +561,9 @@ int pass_once(fdtd_ctx *c, int K)
         a.slot[s] = (a.ring && s >= 1 && s < K) ? (int)((c->step + s - 1) % c->probe_cap) : 0;
     a.rows = c->tb_rows;
     {
-        // the last sixteenth of the slab (at most 1024 rows) goes in bands a quarter as high
-        int tail = std::min(1024, c->sn / 16), short_rows = std::max(4, c->tb_rows / 4);
+        // the last eighth of the slab (at most 2048 rows) goes in bands a third as high
+        // (16384^2, K = 8, 96 rows: no tail 3.63 ms, 1024 rows in 16s 3.50, 2048 in 32s 3.41)
+        int tail = std::min(2048, c->sn / 8), short_rows = std::max(4, c->tb_rows / 3);
         if (const char *v = std::getenv("FDTD_TB_TAIL")) tail = std::atoi(v);
         if (const char *v = std::getenv("FDTD_TB_TAIL_ROWS")) short_rows = std::max(2, std::atoi(v));
         if (tail + c->tb_rows > c->sn || short_rows >= c->tb_rows) tail = 0;
@@ -680,7 +681,9 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             set_error("FDTD_KERNEL_MULTISTEP exists for the 2-D TMz mode only");
             return -3;
         }
-        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : kDefaultStepsPerPass;
+        // (4096^2: 270 Gcell-updates/s at 6 steps per pass, 252 at 8; 8192^2: 422 against 448)
+        const bool mid = (double)p->nx * (opt->slab_count > 0 ? opt->slab_count : p->ny) < 48e6;
+        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : mid ? 6 : kDefaultStepsPerPass;
         if (c->tb_steps < 2 || c->tb_steps > kMaxStepsPerPass) {
             set_error("steps_per_pass must be 2 .. 8");
             return -3;
@@ -700,10 +703,14 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         // 32 to 64 rows per wave keep the recomputed rows (2K - 1 per wave) cheap; smaller grids trade
         // that for enough waves to fill the 256 CUs
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
-        // (measured at K = 6: 16384^2 64 rows, 8192^2 32, 4096^2 and 3072^2 16)
-        c->tb_rows = c->tb_steps >= 5 ? 64 : 32;
-        const int least = (double)c->nx * c->sn >= 6e6 ? 16 : 4;
-        while (c->tb_rows > least && ((c->sn + c->tb_rows - 1) / c->tb_rows) * strips < 8192) c->tb_rows /= 2;
+        // (measured: 16384^2 96 rows at K = 8 and 64 at K = 6, 8192^2 32, 4096^2 and 3072^2 16):
+        // the tallest of these that still gives 8192 waves
+        const int heights[] = {96, 64, 32, 16, 8, 4};
+        const int first = c->tb_steps >= 7 ? 0 : c->tb_steps >= 5 ? 1 : 2;
+        const int last = (double)c->nx * c->sn >= 6e6 ? 3 : 5;
+        int pick = first;
+        while (pick < last && ((c->sn + heights[pick] - 1) / heights[pick]) * strips < 8192) ++pick;
+        c->tb_rows = heights[pick];
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->sn != c->gn && c->sn < c->tb_steps) {
         set_error("a slab of the multi-step mode must hold at least steps_per_pass rows");

@@ -135,6 +135,11 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
         const bool gy_in = y >= 1 && y <= g.gny - 2;
         const bool gy_ez = y >= 0 && y <= g.gny - 1;
         StageOut o;
+        // the four table rows of this lane's cells first: the E update at the end of the stage needs
+        // them, and the H and D arithmetic in between covers the LDS latency
+        MatEntry m[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m[i] = ONE ? a.one : tab[(in.cd >> (8 * i)) & 0xffu];
         const float e_right = __shfl_down(in.ez.x, 1);
         const float er[4] = {in.ez.y, in.ez.z, in.ez.w, e_right};
 #pragma unroll
@@ -160,26 +165,10 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
             o.dz[i] = dn;
         }
 
-        bool uniform = true;
-        MatEntry mu = a.one;
-        if (!ONE) {
-            const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)in.cd) & 0xffu;
-            uniform = __all(in.cd == c0 * 0x01010101u);
-            if (uniform) mu = tab[c0];
-        }
-        if (uniform) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(mu, g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
-                                                     : ezp[i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const MatEntry m = tab[(in.cd >> (8 * i)) & 0xffu];
-                o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m, g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
-                                                     : ezp[i];
-            }
-        }
+        for (int i = 0; i < 4; ++i)
+            o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                                                 : ezp[i];
         return o;
     };
 

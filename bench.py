@@ -60,6 +60,44 @@ def measured_traffic(workload, kernel, spp):
         return None
 
 
+def issue_bound(solver, k, kernel_ms):
+    """Vector-issue estimate of one pass of the multi-step sweep: vector instructions of a row
+    iteration (counted in the gfx950 assembly by tools/isa_count.py: fp32/integer 2 cycles, fp64 4
+    cycles per wave64 instruction on a SIMD-32) x row iterations of the launch / (1024 SIMDs x 2.4 GHz)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "isa_counts.json")) as f:
+            c = json.load(f)[f"K{k}_one_plain"]["inner_march_per_row_iteration"]
+    except (OSError, ValueError, KeyError):
+        return None
+    waves, iters = solver.sweep_work
+    ms = iters * c["valu_issue_cycles"] / (1024 * 2.4e9) * 1e3
+    return {"valu_f32_per_row_iteration": c["valu_f32"], "valu_f64_per_row_iteration": c["valu_f64"],
+            "valu_issue_cycles_per_row_iteration": c["valu_issue_cycles"], "waves": waves, "row_iterations": iters,
+            "model_ms": ms, "frac_of_kernel_time": ms / kernel_ms}
+
+
+def one_step_leg(params, device, cells):
+    """The one-step sweep (one pass over memory per time step: 41 algorithmic bytes per cell-update)
+    on the same workload, timed the same way: 5 warm-up steps, 20 timed."""
+    import numpy as np
+    import fdtd_amd
+    from fdtd_amd import binding as B
+    s = fdtd_amd.Solver(params, ecoef=B.ECOEF_CONSISTENT, kernel=B.KERNEL_FUSED, device=device)
+    s.step(5)
+    s.profile_begin(20)
+    s.step(20)
+    ms, _ = s.profile_read_launches(20)
+    avg = float(np.mean(ms))
+    achieved = cells * BYTES_PER_CELL_2D / (avg * 1e-3) / 1e9
+    name = s.sweep_kernel_name
+    out = {"kernel": name, "kernel_avg_ms": avg, "launches_averaged": int(len(ms)), "algorithmic_bytes_per_cell_update": BYTES_PER_CELL_2D,
+           "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "Mcell_updates_per_s": cells / (avg * 1e-3) / 1e6,
+           "traffic": measured_traffic(f"{params.nx}x{params.ny} 2-D TMz vacuum + centre point source", name, 1)}
+    s.close()
+    return out
+
+
 class stdout_to_stderr:
     """Libraries (gloo, RCCL) print banners on fd 1 while they initialise; stdout is reserved
     for the one JSON line, so fd 1 points at stderr inside this block."""
@@ -91,6 +129,10 @@ def main():
     ap.add_argument("--snapshot-every", type=int, default=0,
                     help="take an ez snapshot (side-stream D2H) every N steps inside the timed region")
     ap.add_argument("--probes", type=int, default=1, help="probes recorded every step (1..16), spread over the grid")
+    ap.add_argument("--allow-host-halo", action="store_true",
+                    help="N > 1: if RCCL cannot initialise, run with halos staged through the host (flagged in the output) "
+                         "instead of failing")
+    ap.add_argument("--no-one-step-leg", action="store_true", help="skip the extra one-step-sweep measurement")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --ny (or --nz) is the extent of the WHOLE grid, cut into --gpus slabs")
     args = ap.parse_args()
@@ -144,16 +186,23 @@ def main():
     params = fdtd_amd.make_params(*gdims, src)
     kernel = {"auto": B.KERNEL_AUTO, "split": B.KERNEL_SPLIT, "fused": B.KERNEL_FUSED,
               "multistep": B.KERNEL_MULTISTEP}[args.kernel]
+    if world > 1 and kernel == B.KERNEL_AUTO:
+        # every rank must run the same kernel with the same halo depth: say so instead of leaving
+        # it to each rank's own decision
+        kernel = B.KERNEL_FUSED if is3d else B.KERNEL_MULTISTEP
+        if not is3d and args.steps_per_pass == 0:
+            args.steps_per_pass = 8
     solver = fdtd_amd.Solver(params, ecoef=B.ECOEF_CONSISTENT, kernel=kernel, device=local_rank,
                              slab=slab if world > 1 else None, chunk_rows=args.chunk_rows,
                              steps_per_pass=args.steps_per_pass)
-    spp = solver.steps_per_pass          # time steps one launch of the sweep advances
+    spp = solver.steps_per_pass          # time steps one full launch of the sweep advances
     halo = "none"
+    halo_fallback = False
     stepper = solver
     if world > 1:
-        # Halo exchange inside the library over RCCL.  Should RCCL not come up on this node,
-        # every rank falls back to the host-staged exchange (same kernels, halo rows moved by
-        # gloo) and the JSON line says so -- a slower run is more useful than no run.
+        # Halo exchange inside the library over RCCL.  Should RCCL not come up on this node the run
+        # fails -- unless --allow-host-halo, with which every rank falls back to the host-staged
+        # exchange (same kernels, halo rows moved by gloo) and the JSON line says so at top level.
         err = ""
         try:
             ids = [fdtd_amd.binding.comm_unique_id() if rank == 0 else None]
@@ -170,13 +219,16 @@ def main():
         flags = [None] * world
         dist.all_gather_object(flags, err)
         if any(flags):
+            msg = f"bench.py: RCCL unavailable ({[f for f in flags if f][0]})"
+            if not args.allow_host_halo:
+                raise SystemExit(msg + "; pass --allow-host-halo to measure with the host-staged exchange instead")
             if rank == 0:
-                print(f"bench.py: RCCL unavailable ({[f for f in flags if f][0]}); host-staged halo exchange",
-                      file=sys.stderr)
+                print(msg + "; host-staged halo exchange", file=sys.stderr)
             stepper = fdtd_amd.SlabRunner(solver, rank, world, transport="host")
+            halo_fallback = True
             halo = "host-staged over gloo (RCCL failed to initialise), 1 E row per neighbour per step"
         else:
-            halo = "RCCL send/recv, 1 E row per neighbour per step"
+            halo = "RCCL send/recv on a second stream beside the sweep of the interior rows, 1 E row per neighbour per step"
         if solver.steps_per_pass > 1:
             halo = halo.replace("1 E row per neighbour per step",
                                 f"{solver.steps_per_pass} rows of 6 arrays + codes per neighbour per pass")
@@ -212,7 +264,7 @@ def main():
     solver.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    sweep_ms = solver.profile_read(args.steps)
+    sweep_ms, sweep_steps = solver.profile_read_launches(args.steps)
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -229,10 +281,25 @@ def main():
     if rank == 0:
         total_cells = cells_per_rank * world
         value = total_cells * args.steps / elapsed / 1e6
-        sweep_avg_ms = float(np.mean(sweep_ms)) if len(sweep_ms) else float("nan")
-        achieved = cells_per_rank * spp * bytes_per_cell / (sweep_avg_ms * 1e-3) / 1e9
+        kernel_name = solver.sweep_kernel_name
         workload = (f"{gdims[0]}x{gdims[1]}x{gdims[2]} 3-D" if is3d else f"{gdims[0]}x{gdims[1]} 2-D TMz") + \
             " vacuum + centre point source"
+        # Launches of the main sweep inside the timed region, grouped by the time steps they advanced:
+        # fdtd_step(n) runs full passes and one shorter remainder pass (a single step: the one-step sweep).
+        groups = {}
+        for ms, k in zip(sweep_ms, sweep_steps):
+            groups.setdefault(int(k), []).append(float(ms))
+        launches = [{"steps": k, "count": len(v), "avg_ms": float(np.mean(v))} for k, v in sorted(groups.items(), reverse=True)]
+        full = groups.get(spp) or next(iter(groups.values()), [float("nan")])
+        full_k = spp if spp in groups else (launches[0]["steps"] if launches else spp)
+        sweep_avg_ms = float(np.mean(full))
+        multistep = spp > 1 and not is3d
+        # Algorithmic bytes of ONE launch: every live array once in and once out.  A pass of the
+        # multi-step sweep reads levels n, n-1, H and the codes (25 B per cell) and writes levels
+        # n+K, n+K-1 and H (24 B) whatever K is; a one-step sweep moves 41 B (2-D) / 97 B (3-D).
+        bytes_per_cell_launch = BYTES_PER_CELL_PASS_2D if multistep else bytes_per_cell
+        achieved = cells_per_rank * bytes_per_cell_launch / (sweep_avg_ms * 1e-3) / 1e9
+        traffic = measured_traffic(workload, kernel_name, full_k)
         out = {
             "metric": "Mcell-updates/s (E+H)",
             "value": value,
@@ -246,11 +313,12 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "halo_fallback": halo_fallback,
             "config": {
                 "workload": workload,
                 "cells_per_gpu": cells_per_rank,
                 "ecoef": "consistent",
-                "kernel": solver.sweep_kernel_name,
+                "kernel": kernel_name,
                 "steps_per_pass": spp,
                 "parallelism": f"slab{world}" if world > 1 else "single",
                 "halo": halo,
@@ -264,24 +332,32 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(workload, solver.sweep_kernel_name, spp),
-                "kernel": solver.sweep_kernel_name,
+                "traffic": traffic,
+                "kernel": kernel_name,
                 "kernel_avg_ms": sweep_avg_ms,
-                "algorithmic_bytes_per_cell": bytes_per_cell,
-                "cell_updates_per_launch": cells_per_rank * spp,
-                "steps_per_launch": spp,
+                "steps_per_launch": full_k,
+                "launches_averaged": len(full),
+                "algorithmic_bytes_per_cell_per_launch": bytes_per_cell_launch,
+                "algorithmic_bytes_per_launch": cells_per_rank * bytes_per_cell_launch,
+                "launches": launches,
             },
         }
-        if spp > 1 and not is3d:
-            # The multi-step sweep moves 49 B per cell and pass instead of 41 B per cell and step,
-            # so `frac` (algorithmic bytes of one-step sweeps / time / peak) can exceed 1; this is
-            # the bandwidth the kernel really draws according to the same byte model.
-            moved = cells_per_rank * BYTES_PER_CELL_PASS_2D / (sweep_avg_ms * 1e-3) / 1e9
-            out["roofline"]["moved_model"] = {"bytes_per_cell_per_launch": BYTES_PER_CELL_PASS_2D,
-                                              "GB/s": moved, "frac_of_peak": moved / HBM_PEAK_GBS}
-            out["roofline"]["note"] = (f"one launch advances {spp} time steps: `achieved` counts the 41 B per "
-                                       "cell-update a one-step sweep must move, the kernel itself moves 49 B per "
-                                       "cell and launch (moved_model; `traffic` is the PMC measurement)")
+        if traffic:
+            out["roofline"]["traffic_GBs"] = traffic / (sweep_avg_ms * 1e-3) / 1e9
+            out["roofline"]["traffic_frac_of_peak"] = traffic / (sweep_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        if multistep:
+            # what the same cell-updates would cost a sweep that advances one step per pass
+            eq = cells_per_rank * full_k * BYTES_PER_CELL_2D / (sweep_avg_ms * 1e-3) / 1e9
+            out["roofline"]["one_step_equivalent"] = {
+                "bytes_per_cell_update": BYTES_PER_CELL_2D, "GB/s": eq, "ratio_to_peak": eq / HBM_PEAK_GBS,
+                "note": f"{full_k} steps per launch: 41 B x cell-updates / time; exceeds the peak because a pass "
+                        "moves 49 B per cell whatever the number of steps"}
+            issue = issue_bound(solver, full_k, sweep_avg_ms)
+            if issue:
+                out["roofline"]["issue_bound"] = issue
+        if world == 1 and not is3d and not args.no_one_step_leg and kernel_name != "fdtd2d_sweep":
+            solver.close()
+            out["roofline_one_step"] = one_step_leg(params, local_rank, cells_per_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(4096, 4096) if not is3d else None
         print(json.dumps(out), flush=True)

@@ -74,6 +74,8 @@ SYMBOLS = [
     ("fdtd_steps_per_pass", _I, [_VP]),
     ("fdtd_profile_begin", _I, [_VP, _I]),
     ("fdtd_profile_read", _I, [_VP, _VP, _I, C.POINTER(_I)]),
+    ("fdtd_profile_read_launches", _I, [_VP, _VP, _VP, _I, C.POINTER(_I)]),
+    ("fdtd_sweep_work", _I, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("fdtd_sweep_kernel_name", C.c_char_p, [_VP]),
     ("fdtd_read_field", _I, [_VP, _I, _I, _VP, _SZ]),
     ("fdtd_write_field", _I, [_VP, _I, _I, _VP, _SZ]),
@@ -91,6 +93,9 @@ SYMBOLS = [
     ("fdtd_halo_put", _I, [_VP, _I, _VP, _SZ]),
     ("fdtd_comm_unique_id", _I, [C.c_char_p]),
     ("fdtd_comm_init", _I, [_VP, C.c_char_p, _I, _I]),
+    ("fdtd_comm_local_group", _I, [_I, C.POINTER(_VP)]),
+    ("fdtd_comm_local_group_free", None, [_VP]),
+    ("fdtd_comm_init_local", _I, [_VP, _VP, _I, _I]),
     ("fdtd_comm_selftest", _I, [_VP]),
 ]
 
@@ -256,9 +261,24 @@ class Solver:
         _check(self.lib.fdtd_profile_read(self._ctx, ms.ctypes.data, capacity, C.byref(n)))
         return ms[:n.value]
 
+    def profile_read_launches(self, capacity):
+        """(milliseconds, time steps advanced) of every timed sweep launch."""
+        ms = np.zeros(capacity, dtype=np.float32)
+        steps = np.zeros(capacity, dtype=np.int32)
+        n = _I(0)
+        _check(self.lib.fdtd_profile_read_launches(self._ctx, ms.ctypes.data, steps.ctypes.data, capacity, C.byref(n)))
+        return ms[:n.value], steps[:n.value]
+
     @property
     def steps_per_pass(self):
         return self.lib.fdtd_steps_per_pass(self._ctx)
+
+    @property
+    def sweep_work(self):
+        """(waves, row iterations) of one launch of the main sweep over this slab."""
+        w, it = C.c_int64(0), C.c_int64(0)
+        _check(self.lib.fdtd_sweep_work(self._ctx, C.byref(w), C.byref(it)))
+        return w.value, it.value
 
     @property
     def sweep_kernel_name(self):
@@ -331,6 +351,9 @@ class Solver:
     def comm_init(self, unique_id, rank, world):
         _check(self.lib.fdtd_comm_init(self._ctx, unique_id, rank, world))
 
+    def comm_init_local(self, group, rank, world):
+        _check(self.lib.fdtd_comm_init_local(self._ctx, group, rank, world))
+
     def comm_selftest(self):
         _check(self.lib.fdtd_comm_selftest(self._ctx))
 
@@ -339,3 +362,18 @@ def comm_unique_id():
     buf = C.create_string_buffer(128)
     _check(load_library().fdtd_comm_unique_id(buf))
     return buf.raw
+
+
+class LocalGroup:
+    """Rendezvous object of the in-process transport (ranks = contexts of this process, one
+    host thread each)."""
+
+    def __init__(self, world):
+        self.world = world
+        self.handle = _VP()
+        _check(load_library().fdtd_comm_local_group(world, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            load_library().fdtd_comm_local_group_free(self.handle)
+            self.handle = None

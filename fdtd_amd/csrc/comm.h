@@ -8,9 +8,17 @@
 namespace fdtd {
 
 struct Comm;
+struct LocalGroup;
 
 int comm_unique_id(char id[128]);
 int comm_create(const char id[128], int rank, int world, Comm **out);
+// In-process transport: the ranks are contexts of ONE process (one host thread each, on one GPU or
+// on several), a message is a device-to-device copy after a rendezvous of the two threads.  Same
+// call sequence as the RCCL transport, so the exchange schedule can be exercised without a
+// second process.
+LocalGroup *local_group_create(int world);
+void local_group_destroy(LocalGroup *g);
+int comm_create_local(LocalGroup *g, int rank, Comm **out);
 void comm_destroy(Comm *c);
 int comm_group_start(Comm *c);
 int comm_group_end(Comm *c);

@@ -36,6 +36,7 @@ using namespace fdtd;
 
 namespace {
 constexpr size_t kSlack = 256; // floats (or bytes) of zero padding around each array
+
 }
 
 struct fdtd_ctx {
@@ -44,7 +45,11 @@ struct fdtd_ctx {
     int kernel = FDTD_KERNEL_SPLIT;
     int ecoef = FDTD_ECOEF_REFERENCE;
     int device = 0;
-    hipStream_t stream = nullptr, side = nullptr;
+    // stream: the sweeps; side: snapshot copies; xstream (higher priority): the launches for the
+    // rows next to a neighbour slab and the halo exchange that follows them
+    hipStream_t stream = nullptr, side = nullptr, xstream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = true; // run the halo exchange beside the sweep of the interior rows
 
     int nx = 0, ny = 0, nz = 0; // global extents
     int s0 = 0, sn = 0, gn = 0; // slab axis: first global row held, rows held, global rows
@@ -61,6 +66,7 @@ struct fdtd_ctx {
     float *d[3][4] = {};
     uint8_t *code = nullptr;
     MatEntry *table = nullptr;
+    MatCoef *table_wide = nullptr;
     MatEntry table0 = {};
     float *rp[6] = {};
     size_t rp_n[6] = {};
@@ -70,12 +76,17 @@ struct fdtd_ctx {
     int hgen = 0; // index of the newest H generation
     int tb_steps = 1;  // MULTISTEP: time steps per pass (also the halo depth in rows)
     int tb_rows = 32;  // MULTISTEP: owned rows per wave
+    int tb_map = 0;    // MULTISTEP: 1 = every XCD walks its own panel of strips (16384^2: 4.47 ms per pass against 3.42)
     int halo = 1;      // halo rows (2-D) on either side of the slab
     size_t lead = 0;   // floats between the start of an array and local row -1: (halo - 1) * pitch
     int64_t step = 0;
 
     MaterialRow mats[FDTD_MAX_CODES];
-    int ntab = 1; // rows of the device table in use: 1 + (highest material code on the grid + 1)
+    int ntab = 1;      // 1 + the highest device code on the owned rows (1: every owned cell holds the default material)
+    int ntab_halo = 1; // the same for the material codes received into the deep halo rows
+    int halo_top[2] = {0, 0};
+    bool spp_fixed = false; // steps per pass do not depend on the materials (slabs, or set by the caller)
+    int ntab_eff() const { return std::max(ntab, ntab_halo); }
     std::vector<uint8_t> codes_host; // slab cells, x fastest; empty = all default
     std::vector<float> rp_host[6];
     SourceList src; // global coordinates
@@ -86,22 +97,33 @@ struct fdtd_ctx {
     int probe_cap = 0;
     int64_t probe_first = 0; // step index of the oldest row the ring may hold
 
-    // per-step sweep timing
+    // per-launch sweep timing
     std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_steps; // time steps each timed launch advanced
     int prof_cap = 0, prof_n = 0;
 
-    // snapshot
-    float *snap_dev = nullptr, *snap_host = nullptr;
-    size_t snap_count = 0;
-    float *snap_dst = nullptr;
-    bool snap_pending = false;
+    // snapshots: two staging sets (compact device copy + pinned host buffer), used in turn, so a new
+    // snapshot only waits when two are still on their way
+    struct Snap {
+        float *dev = nullptr, *host = nullptr;
+        size_t count = 0;
+        float *dst = nullptr;
+        bool pending = false;
+        hipEvent_t copied = nullptr; // the compact device copy has been taken
+        hipEvent_t done = nullptr;   // the data is in `host`
+    } snap[2];
+    int snap_next = 0, snap_last = -1;
     hipEvent_t snap_ev = nullptr;
+    int64_t launches = 0;        // sweeps launched so far
+    int64_t snap_guard_at = -1;  // the launch with this number must wait for snap[snap_guard].copied
+    int snap_guard = 0;
 
     Comm *comm = nullptr;
     int rank = 0, world = 1;
 
     // MULTISTEP slabs: deep halos (tb_steps rows of every live array per side)
     float *halo_send[2] = {}, *halo_recv[2] = {};
+    bool auto_kernel = false;
     bool halo_stale = true; // set by everything that changes the state behind the stepper's back
     bool deep() const { return kernel == FDTD_KERNEL_MULTISTEP; }
     size_t deep_count() const { return (size_t)6 * tb_steps * nx + ((size_t)tb_steps * nx + 3) / 4; }
@@ -197,12 +219,15 @@ inline uint8_t device_code(uint8_t code) { return code == kDefaultCode ? 0 : (ui
 int upload_table(fdtd_ctx *c)
 {
     std::vector<MatEntry> t(FDTD_MAX_CODES);
+    std::vector<MatCoef> w(FDTD_MAX_CODES);
     for (int i = 0; i < FDTD_MAX_CODES; ++i) {
         const MatCoef k = make_coef(c->mats[i], c->p.dt, c->p.eps0, c->ecoef);
         t[device_code((uint8_t)i)] = {k.a, k.c, k.d, c->mats[i].tau_d};
+        w[device_code((uint8_t)i)] = k;
     }
     c->table0 = t[0];
     HIPCHK(hipMemcpyAsync(c->table, t.data(), t.size() * sizeof(MatEntry), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->table_wide, w.data(), w.size() * sizeof(MatCoef), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -299,11 +324,10 @@ int ensure_deep_buffers(fdtd_ctx *c)
     return 0;
 }
 
-// Pack the boundary rows of the sides in `sides` into halo_send, or unpack halo_recv into the halo rows.
-int deep_halo_kernel(fdtd_ctx *c, int sides, bool unpack)
+// Pack the boundary rows of the sides in `sides` into b0 (lower side) / b1 (upper side), or unpack
+// those buffers into the halo rows.
+int deep_halo_kernel(fdtd_ctx *c, int sides, bool unpack, float *b0, float *b1, hipStream_t st)
 {
-    int rc = ensure_deep_buffers(c);
-    if (rc) return rc;
     HaloDeep a;
     a.arr[0] = c->h[0][c->hgen];
     a.arr[1] = c->h[1][c->hgen];
@@ -312,59 +336,157 @@ int deep_halo_kernel(fdtd_ctx *c, int sides, bool unpack)
     a.arr[4] = c->D(2, 0);
     a.arr[5] = c->D(2, 1);
     a.code = c->code;
-    for (int s = 0; s < 2; ++s) a.buf[s] = unpack ? c->halo_recv[s] : c->halo_send[s];
+    a.buf[0] = b0;
+    a.buf[1] = b1;
     a.nx = c->nx;
     a.pitch = c->pitch;
     a.nyl = c->sn;
     a.depth = c->tb_steps;
     a.sides = sides;
     a.unpack = unpack ? 1 : 0;
-    launch_halo_deep(a, c->stream);
+    launch_halo_deep(a, st);
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-int exchange_halos_rccl(fdtd_ctx *c)
+// Highest material code among the code bytes at the end of a packed deep-halo block.
+int top_code(const uint8_t *codes, size_t n)
+{
+    int top = 0;
+    for (size_t i = 0; i < n; ++i) top = std::max(top, (int)codes[i]);
+    return top;
+}
+
+// Halo exchange with ranks rank-1 and rank+1 over the communicator, queued on `st`.
+// `scan`: the materials may have changed since the last exchange, so look at the codes that
+// arrive (this waits for the exchange): a slab whose own cells all hold one material must still
+// take the table kernel when its halo rows, which it recomputes, hold another.
+int exchange_halos(fdtd_ctx *c, hipStream_t st, bool scan)
 {
     if (!c->comm || c->world == 1) return 0;
+    const int lower = c->rank - 1, upper = c->rank + 1;
     if (c->deep()) {
-        const int lower = c->rank - 1, upper = c->rank + 1;
         const int sides = (lower >= 0 ? 1 : 0) | (upper < c->world ? 2 : 0);
-        int rc = deep_halo_kernel(c, sides, false);
+        int rc = ensure_deep_buffers(c);
+        if (!rc) rc = deep_halo_kernel(c, sides, false, c->halo_send[0], c->halo_send[1], st);
         if (rc) return rc;
         rc = comm_group_start(c->comm);
         const int peer[2] = {lower, upper};
         for (int s = 0; s < 2 && rc == 0; ++s) {
             if (!((sides >> s) & 1)) continue;
-            rc = comm_send(c->comm, c->halo_send[s], c->deep_count(), peer[s], c->stream);
-            if (rc == 0) rc = comm_recv(c->comm, c->halo_recv[s], c->deep_count(), peer[s], c->stream);
+            rc = comm_send(c->comm, c->halo_send[s], c->deep_count(), peer[s], st);
+            if (rc == 0) rc = comm_recv(c->comm, c->halo_recv[s], c->deep_count(), peer[s], st);
         }
         const int rc2 = comm_group_end(c->comm);
         if (rc || rc2) return rc ? rc : rc2;
         c->halo_stale = false;
-        return deep_halo_kernel(c, sides, true);
+        if ((rc = deep_halo_kernel(c, sides, true, c->halo_recv[0], c->halo_recv[1], st))) return rc;
+        if (scan) {
+            const size_t n = (size_t)c->tb_steps * c->nx;
+            std::vector<uint8_t> tmp(n);
+            for (int s = 0; s < 2; ++s) {
+                c->halo_top[s] = 0;
+                if (!((sides >> s) & 1)) continue;
+                HIPCHK(hipMemcpyAsync(tmp.data(), (const uint8_t *)(c->halo_recv[s] + (size_t)6 * n), n,
+                                      hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                c->halo_top[s] = top_code(tmp.data(), n);
+            }
+            c->ntab_halo = 1 + std::max(c->halo_top[0], c->halo_top[1]);
+        }
+        return 0;
     }
     const size_t count = c->is2d() ? (size_t)c->nx : (size_t)c->ny * c->pitch;
     const int c0 = c->is2d() ? 2 : 0;
-    const int lower = c->rank - 1, upper = c->rank + 1;
     int rc = comm_group_start(c->comm);
     for (int comp = c0; comp < 3 && rc == 0; ++comp) {
         if (lower >= 0) {
-            rc = comm_send(c->comm, halo_rows(c, comp, 0, false), count, lower, c->stream);
-            if (rc == 0) rc = comm_recv(c->comm, halo_rows(c, comp, 0, true), count, lower, c->stream);
+            rc = comm_send(c->comm, halo_rows(c, comp, 0, false), count, lower, st);
+            if (rc == 0) rc = comm_recv(c->comm, halo_rows(c, comp, 0, true), count, lower, st);
         }
         if (rc == 0 && upper < c->world) {
-            rc = comm_send(c->comm, halo_rows(c, comp, 1, false), count, upper, c->stream);
-            if (rc == 0) rc = comm_recv(c->comm, halo_rows(c, comp, 1, true), count, upper, c->stream);
+            rc = comm_send(c->comm, halo_rows(c, comp, 1, false), count, upper, st);
+            if (rc == 0) rc = comm_recv(c->comm, halo_rows(c, comp, 1, true), count, upper, st);
         }
     }
     int rc2 = comm_group_end(c->comm);
     return rc ? rc : rc2;
 }
 
+// Which sides have a neighbour rank, and whether a step is cut into a launch for the rows
+// (planes) next to them -- followed by the halo exchange, both on xstream -- and a launch for
+// the interior rows on the main stream.
+struct Split {
+    bool lower = false, upper = false, on = false;
+    int edge = 0; // rows (planes) per edge region
+};
+
+Split split_of(const fdtd_ctx *c, int edge, int min_interior)
+{
+    Split sp;
+    if (!c->comm || c->world == 1) return sp;
+    sp.lower = c->rank > 0;
+    sp.upper = c->rank < c->world - 1;
+    sp.edge = edge;
+    sp.on = c->overlap && c->one_pass() && (sp.lower || sp.upper) && c->sn >= 2 * edge + min_interior;
+    return sp;
+}
+
+// A snapshot reads the newest arrays on the side stream while the next sweep runs; the sweep
+// after that one overwrites them and has to wait for the copy.
+int snapshot_guard(fdtd_ctx *c)
+{
+    if (c->snap_guard_at >= 0 && c->launches >= c->snap_guard_at) {
+        HIPCHK(hipStreamWaitEvent(c->stream, c->snap[c->snap_guard].copied, 0));
+        c->snap_guard_at = -1;
+    }
+    c->launches++;
+    return 0;
+}
+
+int fork_xstream(fdtd_ctx *c)
+{
+    HIPCHK(hipEventRecord(c->ev_fork, c->stream));
+    HIPCHK(hipStreamWaitEvent(c->xstream, c->ev_fork, 0));
+    return 0;
+}
+
+int join_xstream(fdtd_ctx *c)
+{
+    HIPCHK(hipEventRecord(c->ev_join, c->xstream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return 0;
+}
+
+Mur2D mur2d_args(const fdtd_ctx *c, const Grid2D &g, float *target, const float *source)
+{
+    Mur2D m;
+    m.g = g;
+    m.j_begin = 0;
+    m.j_end = c->sn;
+    m.ez_t = target;
+    m.ez_s = source;
+    m.rpx0 = c->rp[FDTD_RP_X0];
+    m.rpxe = c->rp[FDTD_RP_XEND];
+    m.rpy0 = c->rp[FDTD_RP_Y0];
+    m.rpye = c->rp[FDTD_RP_YEND];
+    m.dt = c->p.dt;
+    m.dx = c->p.dx;
+    m.dy = c->p.dy;
+    m.mu0 = c->p.mu0;
+    m.eps0 = c->p.eps0;
+    return m;
+}
+
 int step_once(fdtd_ctx *c)
 {
+    int rc = snapshot_guard(c);
+    if (rc) return rc;
     const bool prof = c->prof_n < c->prof_cap;
+    // one-step kernels: 8 rows (2-D) or one plane (3-D) next to each neighbour go first
+    const Split sp = split_of(c, c->is2d() ? 8 : 1, c->is2d() ? 16 : 2);
+    const int lo = sp.on && sp.lower ? sp.edge : 0, hi = sp.on && sp.upper ? c->sn - sp.edge : c->sn;
+    if (sp.on && (rc = fork_xstream(c))) return rc;
     if (c->is2d()) {
         Sweep2D a;
         a.g = grid2d(c);
@@ -377,38 +499,44 @@ int step_once(fdtd_ctx *c)
         a.ntab = c->ntab;
         a.one = c->table0;
         a.chunk_rows = c->chunk_rows;
+        a.row_begin = lo;
+        a.row_end = hi;
         a.variant = c->variant;
         a.band = c->band;
         a.nopad = c->nopad;
         a.src = sources_for_step(c);
-        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
+        Mur2D m = mur2d_args(c, a.g, c->E(2, 1), c->E(2, 0));
         if (c->one_pass()) {
             a.hx_r = c->h[0][c->hgen];
             a.hy_r = c->h[1][c->hgen];
             a.hx_w = c->h[0][c->hgen ^ 1];
             a.hy_w = c->h[1][c->hgen ^ 1];
+            if (sp.on) {
+                Sweep2D e = a;
+                e.band = 0;
+                e.nopad = 1;
+                const int ranges[2][2] = {{0, lo}, {hi, c->sn}};
+                for (const auto &r : ranges) {
+                    if (r[1] <= r[0]) continue;
+                    e.row_begin = m.j_begin = r[0];
+                    e.row_end = m.j_end = r[1];
+                    launch_sweep2d(e, c->xstream);
+                    launch_mur2d(m, c->xstream);
+                }
+            }
+            if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
             launch_sweep2d(a, c->stream);
             c->hgen ^= 1;
         } else {
             a.hx_r = a.hx_w = c->h[0][c->hgen];
             a.hy_r = a.hy_w = c->h[1][c->hgen];
+            if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
             launch_h2d(a, c->stream);
             launch_de2d(a, c->stream);
         }
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
-        Mur2D m;
-        m.g = a.g;
-        m.ez_t = c->E(2, 1);
-        m.ez_s = c->E(2, 0);
-        m.rpx0 = c->rp[FDTD_RP_X0];
-        m.rpxe = c->rp[FDTD_RP_XEND];
-        m.rpy0 = c->rp[FDTD_RP_Y0];
-        m.rpye = c->rp[FDTD_RP_YEND];
-        m.dt = c->p.dt;
-        m.dx = c->p.dx;
-        m.dy = c->p.dy;
-        m.mu0 = c->p.mu0;
-        m.eps0 = c->p.eps0;
+        m.j_begin = lo;
+        m.j_end = hi;
         launch_mur2d(m, c->stream);
     } else {
         Sweep3D a;
@@ -423,7 +551,19 @@ int step_once(fdtd_ctx *c)
         a.code = c->code;
         a.table = c->table;
         a.src = sources_for_step(c);
-        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
+        Mur3D m;
+        m.g = a.g;
+        for (int k = 0; k < 3; ++k) {
+            m.e_t[k] = c->E(k, 1);
+            m.e_s[k] = c->E(k, 0);
+        }
+        for (int f = 0; f < 6; ++f) m.rp[f] = c->rp[f];
+        m.dt = c->p.dt;
+        m.dx = c->p.dx;
+        m.dy = c->p.dy;
+        m.dz = c->p.dz;
+        m.mu0 = c->p.mu0;
+        m.eps0 = c->p.eps0;
         if (c->kernel == FDTD_KERNEL_FUSED) {
             Fused3D f;
             f.g = a.g;
@@ -452,35 +592,42 @@ int step_once(fdtd_ctx *c)
                 f.src_word[s] = here ? ((long long)kz * c->ny + a.src.y[s]) * p4 + a.src.x[s] / 4 : -1;
                 f.src_comp[s] = a.src.x[s] % 4;
             }
+            if (sp.on) {
+                const int ranges[2][2] = {{0, lo}, {hi, c->sn}};
+                for (const auto &r : ranges) {
+                    if (r[1] <= r[0]) continue;
+                    f.k_begin = m.k_begin = r[0];
+                    f.k_end = m.k_end = r[1];
+                    launch_sweep3d(f, c->xstream);
+                    launch_mur3d(m, c->xstream);
+                }
+            }
+            f.k_begin = lo;
+            f.k_end = hi;
+            if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
             launch_sweep3d(f, c->stream);
             c->hgen ^= 1;
         } else {
+            if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
             launch_h3d(a, c->stream);
             launch_de3d(a, c->stream);
         }
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
-        Mur3D m;
-        m.g = a.g;
-        for (int k = 0; k < 3; ++k) {
-            m.e_t[k] = c->E(k, 1);
-            m.e_s[k] = c->E(k, 0);
-        }
-        for (int f = 0; f < 6; ++f) m.rp[f] = c->rp[f];
-        m.dt = c->p.dt;
-        m.dx = c->p.dx;
-        m.dy = c->p.dy;
-        m.dz = c->p.dz;
-        m.mu0 = c->p.mu0;
-        m.eps0 = c->p.eps0;
+        m.k_begin = lo;
+        m.k_end = hi;
         launch_mur3d(m, c->stream);
     }
     HIPCHK(hipGetLastError());
-    if (prof) c->prof_n++;
+    if (prof) c->prof_steps[c->prof_n++] = 1;
     c->cur ^= 1;
     c->step++;
 
-    int rc = exchange_halos_rccl(c);
-    if (rc) return rc;
+    if (sp.on) {
+        if ((rc = exchange_halos(c, c->xstream, false))) return rc;
+        if ((rc = join_xstream(c))) return rc;
+    } else if ((rc = exchange_halos(c, c->stream, false))) {
+        return rc;
+    }
     record_probes(c, 0);
     return 0;
 }
@@ -521,9 +668,29 @@ void record_probes(fdtd_ctx *c, int mid)
     }
 }
 
+// Rows of a launch of the multi-step sweep over [y_begin, y_end): bands of tb_rows rows, the last
+// eighth (at most 2048 rows) in bands a third as high
+// (16384^2, K = 8, 96 rows: no tail 3.63 ms, 1024 rows in 16s 3.50, 2048 in 32s 3.41).
+void tb_rows_of(const fdtd_ctx *c, SweepTB &a, int y_begin, int y_end)
+{
+    const int n = y_end - y_begin;
+    int tail = std::min(2048, n / 8), short_rows = std::max(4, c->tb_rows / 3);
+    if (const char *v = std::getenv("FDTD_TB_TAIL")) tail = std::atoi(v);
+    if (const char *v = std::getenv("FDTD_TB_TAIL_ROWS")) short_rows = std::max(2, std::atoi(v));
+    if (tail + c->tb_rows > n || short_rows >= c->tb_rows) tail = 0;
+    a.rows = c->tb_rows;
+    a.y_begin = y_begin;
+    a.y_end = y_end;
+    a.tail_rows = tail > 0 ? short_rows : c->tb_rows;
+    a.big_bands = tail > 0 ? (n - tail) / c->tb_rows : (n + c->tb_rows - 1) / c->tb_rows;
+    a.tail_begin = tail > 0 ? y_begin + a.big_bands * c->tb_rows : y_end;
+}
+
 // MULTISTEP: K <= tb_steps time steps in one pass (sweep2d_tb.hip), then Mur on the newest level.
 int pass_once(fdtd_ctx *c, int K)
 {
+    int rc = snapshot_guard(c);
+    if (rc) return rc;
     const bool prof = c->prof_n < c->prof_cap;
     SweepTB a;
     a.g = grid2d(c);
@@ -542,8 +709,9 @@ int pass_once(fdtd_ctx *c, int K)
     a.dz_b = c->d[2][other + 1];
     a.code = c->code;
     a.table = c->table;
+    a.table_wide = c->table_wide;
     a.one = c->table0;
-    a.ntab = c->ntab;
+    a.ntab = c->ntab_eff();
     a.src = c->src;
     a.src.jz = 0.0f;
     for (int s = 0; s < kMaxStepsPerPass; ++s) a.jz[s] = s < K ? jz_of_step(c, c->step + s) : 0.0f;
@@ -559,45 +727,62 @@ int pass_once(fdtd_ctx *c, int K)
     a.ring = (c->probes.count > 0) ? c->probe_ring : nullptr;
     for (int s = 0; s < kMaxStepsPerPass; ++s)
         a.slot[s] = (a.ring && s >= 1 && s < K) ? (int)((c->step + s - 1) % c->probe_cap) : 0;
-    a.rows = c->tb_rows;
-    {
-        // the last eighth of the slab (at most 2048 rows) goes in bands a third as high
-        // (16384^2, K = 8, 96 rows: no tail 3.63 ms, 1024 rows in 16s 3.50, 2048 in 32s 3.41)
-        int tail = std::min(2048, c->sn / 8), short_rows = std::max(4, c->tb_rows / 3);
-        if (const char *v = std::getenv("FDTD_TB_TAIL")) tail = std::atoi(v);
-        if (const char *v = std::getenv("FDTD_TB_TAIL_ROWS")) short_rows = std::max(2, std::atoi(v));
-        if (tail + c->tb_rows > c->sn || short_rows >= c->tb_rows) tail = 0;
-        a.tail_rows = tail > 0 ? short_rows : c->tb_rows;
-        a.big_bands = tail > 0 ? (c->sn - tail) / c->tb_rows : (c->sn + c->tb_rows - 1) / c->tb_rows;
-    }
     a.strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
+    a.map = c->tb_map;
+    a.strips_per_xcd = (a.strips + 7) / 8;
+
+    // The rows within `edge` of a neighbour slab go first, on xstream, and the deep-halo exchange
+    // follows them there while the main stream sweeps the interior.
+    const int edge = (c->tb_steps + 15) / 16 * 16;
+    const Split sp = split_of(c, edge, c->tb_rows);
+    const int lo = sp.on && sp.lower ? edge : 0, hi = sp.on && sp.upper ? c->sn - edge : c->sn;
+    if (sp.on) {
+        if ((rc = fork_xstream(c))) return rc;
+        SweepTB e = a;
+        e.rows = e.tail_rows = edge;
+        e.y_begin = 0;
+        e.big_bands = lo > 0 ? 1 : 0;
+        e.tail_begin = hi < c->sn ? hi : lo;
+        e.y_end = hi < c->sn ? c->sn : lo;
+        if (launch_sweep2d_tb(e, K, c->xstream)) {
+            set_error("no multi-step kernel for this number of steps per pass");
+            return -3;
+        }
+    }
+    tb_rows_of(c, a, lo, hi);
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
-    launch_sweep2d_tb(a, K, c->stream);
+    if (launch_sweep2d_tb(a, K, c->stream)) {
+        set_error("no multi-step kernel for this number of steps per pass");
+        return -3;
+    }
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
     c->pair ^= 1;
     c->cur = 1;
     c->hgen ^= 1;
     c->step += K;
 
-    Mur2D m;
-    m.g = a.g;
-    m.ez_t = c->E(2, 0);
-    m.ez_s = c->E(2, 1);
-    m.rpx0 = a.rpx0;
-    m.rpxe = a.rpxe;
-    m.rpy0 = a.rpy0;
-    m.rpye = a.rpye;
-    m.dt = c->p.dt;
-    m.dx = c->p.dx;
-    m.dy = c->p.dy;
-    m.mu0 = c->p.mu0;
-    m.eps0 = c->p.eps0;
+    Mur2D m = mur2d_args(c, a.g, c->E(2, 0), c->E(2, 1));
+    if (sp.on) {
+        const int ranges[2][2] = {{0, lo}, {hi, c->sn}};
+        for (const auto &r : ranges) {
+            if (r[1] <= r[0]) continue;
+            m.j_begin = r[0];
+            m.j_end = r[1];
+            launch_mur2d(m, c->xstream);
+        }
+    }
+    m.j_begin = lo;
+    m.j_end = hi;
     launch_mur2d(m, c->stream);
     HIPCHK(hipGetLastError());
-    if (prof) c->prof_n++;
+    if (prof) c->prof_steps[c->prof_n++] = K;
 
-    int rc = exchange_halos_rccl(c);
-    if (rc) return rc;
+    if (sp.on) {
+        if ((rc = exchange_halos(c, c->xstream, false))) return rc;
+        if ((rc = join_xstream(c))) return rc;
+    } else if ((rc = exchange_halos(c, c->stream, false))) {
+        return rc;
+    }
     record_probes(c, K - 1);
     return 0;
 }
@@ -620,14 +805,22 @@ void fdtd_destroy(fdtd_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->side) (void)hipStreamSynchronize(c->side);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     if (c->comm) comm_destroy(c->comm);
     for (void *ptr : c->allocs) (void)hipFree(ptr);
     if (c->probe_ring) (void)hipFree(c->probe_ring);
-    if (c->snap_dev) (void)hipFree(c->snap_dev);
-    if (c->snap_host) (void)hipHostFree(c->snap_host);
+    for (auto &sn : c->snap) {
+        if (sn.dev) (void)hipFree(sn.dev);
+        if (sn.host) (void)hipHostFree(sn.host);
+        if (sn.copied) (void)hipEventDestroy(sn.copied);
+        if (sn.done) (void)hipEventDestroy(sn.done);
+    }
     if (c->snap_ev) (void)hipEventDestroy(c->snap_ev);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
     if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -657,20 +850,13 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     }
     c->ecoef = opt->ecoef;
     c->kernel = opt->kernel;
+    c->auto_kernel = c->kernel == FDTD_KERNEL_AUTO;
     if (c->kernel == FDTD_KERNEL_AUTO) {
-        // 2-D: several steps per pass when the 49 bytes per cell that keeps resident fit, else one
-        c->kernel = FDTD_KERNEL_FUSED;
-        if (c->is2d()) {
-            size_t free_b = 0, total_b = 0;
-            (void)hipSetDevice(opt->device);
-            const size_t rows = (size_t)(opt->slab_count > 0 ? opt->slab_count : p->ny) + 2 * kDefaultStepsPerPass;
-            const double need = 49.0 * (double)rows * (double)((p->nx + 63) / 64 * 64) * 1.03 + 64e6;
-            // below a few million cells a pass is bound by the latency of its row-by-row march,
-            // not by bandwidth, and the one-step sweep is as fast or faster (measured crossover: 2048^2)
-            const bool large = (double)p->nx * (double)(rows - 2 * kDefaultStepsPerPass) >= 6e6;
-            if (large && hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)free_b > need)
-                c->kernel = FDTD_KERNEL_MULTISTEP;
-        }
+        // 2-D: several steps per pass from 6 M cells up; below, a pass is bound by the latency of
+        // its row-by-row march, not by bandwidth, and the one-step sweep is as fast or faster
+        // (measured crossover: 2048^2).  Decided from the extents of the WHOLE grid, so that every
+        // slab of it takes the same kernel.
+        c->kernel = (c->is2d() && (double)p->nx * (double)p->ny >= 6e6) ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_FUSED;
     }
     if (c->kernel != FDTD_KERNEL_SPLIT && c->kernel != FDTD_KERNEL_FUSED && c->kernel != FDTD_KERNEL_MULTISTEP) {
         set_error("unknown kernel selection");
@@ -681,9 +867,12 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             set_error("FDTD_KERNEL_MULTISTEP exists for the 2-D TMz mode only");
             return -3;
         }
-        // (4096^2: 270 Gcell-updates/s at 6 steps per pass, 252 at 8; 8192^2: 422 against 448)
-        const bool mid = (double)p->nx * (opt->slab_count > 0 ? opt->slab_count : p->ny) < 48e6;
+        // (4096^2: 270 Gcell-updates/s at 6 steps per pass, 252 at 8; 8192^2: 422 against 448);
+        // from the extents of the whole grid: every slab must advance the same number of steps
+        // between two halo exchanges
+        const bool mid = (double)p->nx * (double)p->ny < 48e6;
         c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : mid ? 6 : kDefaultStepsPerPass;
+        c->spp_fixed = opt->steps_per_pass > 0 || (opt->slab_count > 0 && opt->slab_count != p->ny);
         if (c->tb_steps < 2 || c->tb_steps > kMaxStepsPerPass) {
             set_error("steps_per_pass must be 2 .. 8");
             return -3;
@@ -742,7 +931,16 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, greatest));
+    }
     HIPCHK(hipEventCreateWithFlags(&c->snap_ev, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    if (const char *v = std::getenv("FDTD_HALO_OVERLAP")) c->overlap = std::atoi(v) != 0;
+    if (const char *v = std::getenv("FDTD_TB_MAP")) c->tb_map = std::atoi(v);
 
     int skew = 0;
     if (const char *s = std::getenv("FDTD_PITCH_SKEW")) skew = std::atoi(s);
@@ -775,6 +973,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     if ((rc = dev_alloc(c, &code_base, c->elems + 2 * kSlack))) return rc;
     c->code = code_base + kSlack + c->lead;
     if ((rc = dev_alloc(c, &c->table, (size_t)FDTD_MAX_CODES))) return rc;
+    if ((rc = dev_alloc(c, &c->table_wide, (size_t)FDTD_MAX_CODES))) return rc;
 
     // Every code maps to the defaults until a spec table is loaded.
     const MaterialRow def = {p->default_sigma, p->default_eps_s, p->default_eps_i, p->default_tau_d};
@@ -809,6 +1008,23 @@ int fdtd_create(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx **out)
         fdtd_options_default(&o);
     fdtd_ctx *c = new fdtd_ctx();
     int rc = create_impl(p, &o, c);
+    if (rc == -10 && c->auto_kernel && c->kernel == FDTD_KERNEL_MULTISTEP) {
+        // FDTD_KERNEL_AUTO took the multi-step sweep and its 49 bytes per cell did not fit.  A whole
+        // grid falls back to the one-step sweep (33 bytes per cell); a slab must not decide on its
+        // own, because its neighbours would keep another halo depth.
+        const bool whole = o.slab_count <= 0 || o.slab_count == (p->nz == 1 ? p->ny : p->nz);
+        const std::string keep = fdtd_last_error();
+        fdtd_destroy(c);
+        (void)hipGetLastError();
+        if (!whole) {
+            set_error(keep + " (FDTD_KERNEL_AUTO chose the multi-step sweep from the extents of the whole grid and "
+                             "this slab's arrays do not fit: pass FDTD_KERNEL_FUSED to every rank)");
+            return rc;
+        }
+        o.kernel = FDTD_KERNEL_FUSED;
+        c = new fdtd_ctx();
+        rc = create_impl(p, &o, c);
+    }
     if (rc) {
         const std::string keep = fdtd_last_error();
         fdtd_destroy(c);
@@ -940,16 +1156,24 @@ int fdtd_setup_mur_from_materials(fdtd_ctx *c)
 int fdtd_step(fdtd_ctx *c, int nsteps)
 {
     if (use_device(c)) return -10;
-    if (c->deep() && c->halo_stale && c->comm && c->world > 1) {
-        // codes, fields or a checkpoint were loaded since the last exchange: the deep halos
-        // (which hold the neighbours' materials and previous levels too) must be refreshed first
-        int rc = exchange_halos_rccl(c);
-        if (rc) return rc;
+    const int spp = fdtd_steps_per_pass(c);
+    if (c->deep() && c->sn != c->gn) {
+        if (c->comm && c->world > 1) {
+            if (c->halo_stale) {
+                // codes, fields or a checkpoint were loaded since the last exchange: the deep halos
+                // (which hold the neighbours' materials and previous levels too) are refreshed first
+                int rc = exchange_halos(c, c->stream, true);
+                if (rc) return rc;
+            }
+        } else if (nsteps > spp) {
+            set_error("fdtd_step: a slab of the multi-step mode without a communicator advances at most "
+                      "steps_per_pass steps per call; exchange the halos (fdtd_halo_get/put) between calls");
+            return -3;
+        }
     }
     for (int i = 0; i < nsteps;) {
         // full passes, then one shorter pass for the remainder (a single step: the one-step sweep)
-        // (with several materials on the grid a pass advances at most kMaxStepsPerPassTable steps)
-        const int k = std::min(nsteps - i, fdtd_steps_per_pass(c));
+        const int k = std::min(nsteps - i, spp);
         int rc = k >= 2 ? pass_once(c, k) : step_once(c);
         if (rc) return rc;
         i += k;
@@ -960,7 +1184,11 @@ int fdtd_step(fdtd_ctx *c, int nsteps)
 int fdtd_steps_per_pass(const fdtd_ctx *c)
 {
     if (c->kernel != FDTD_KERNEL_MULTISTEP) return 1;
-    return c->ntab > 1 ? std::min(c->tb_steps, kMaxStepsPerPassTable) : c->tb_steps;
+    // Several materials on a whole grid: 7 steps per pass with four waves per workgroup beat 8 with
+    // three.  Slabs keep the number they were created with: every rank must advance the same
+    // number of steps between two exchanges whatever materials it holds.
+    if (c->spp_fixed || c->ntab_eff() == 1) return c->tb_steps;
+    return std::min(c->tb_steps, kFastStepsPerPassTable);
 }
 
 int fdtd_sync(fdtd_ctx *c)
@@ -981,19 +1209,50 @@ int fdtd_profile_begin(fdtd_ctx *c, int capacity)
         HIPCHK(hipEventCreate(&ev));
         c->prof_ev.push_back(ev);
     }
+    c->prof_steps.assign((size_t)std::max(capacity, 0), 0);
     c->prof_cap = capacity;
     c->prof_n = 0;
     return 0;
 }
 
-int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
+int fdtd_profile_read_launches(fdtd_ctx *c, float *sweep_ms, int32_t *steps, int capacity, int *count)
 {
     if (use_device(c)) return -10;
     HIPCHK(hipStreamSynchronize(c->stream));
     const int n = std::min(capacity, c->prof_n);
-    for (int i = 0; i < n; ++i) HIPCHK(hipEventElapsedTime(&sweep_ms[i], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+    for (int i = 0; i < n; ++i) {
+        HIPCHK(hipEventElapsedTime(&sweep_ms[i], c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        if (steps) steps[i] = c->prof_steps[i];
+    }
     if (count) *count = n;
     c->prof_cap = 0;
+    return 0;
+}
+
+int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
+{
+    return fdtd_profile_read_launches(c, sweep_ms, nullptr, capacity, count);
+}
+
+int fdtd_sweep_work(const fdtd_ctx *c, int64_t *waves, int64_t *row_iterations)
+{
+    if (!c->deep()) {
+        // one-step kernels: a wave handles one row (2-D: of 256 columns; 3-D: 64 words of a plane) once
+        const int64_t w = c->is2d() ? (int64_t)((c->nx + 255) / 256) * c->sn
+                                    : ((int64_t)c->ny * (c->pitch / 4) + 63) / 64 * c->sn;
+        if (waves) *waves = w;
+        if (row_iterations) *row_iterations = w;
+        return 0;
+    }
+    SweepTB a;
+    tb_rows_of(c, a, 0, c->sn);
+    const int64_t strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
+    const int K = fdtd_steps_per_pass(c);
+    int64_t bands = a.big_bands, iters = 0;
+    for (int b = 0; b < a.big_bands; ++b) iters += std::min(a.rows, c->sn - b * a.rows) + 2 * K - 1;
+    for (int y = a.tail_begin; y < c->sn; y += a.tail_rows, ++bands) iters += std::min(a.tail_rows, c->sn - y) + 2 * K - 1;
+    if (waves) *waves = bands * strips;
+    if (row_iterations) *row_iterations = iters * strips;
     return 0;
 }
 
@@ -1056,46 +1315,79 @@ int fdtd_write_field(fdtd_ctx *c, int field, int level, const float *src, size_t
 
 int fdtd_snapshot_wait(fdtd_ctx *c)
 {
-    if (!c->snap_pending) return 0;
+    if (!c->snap[0].pending && !c->snap[1].pending) return 0;
     if (use_device(c)) return -10;
     HIPCHK(hipStreamSynchronize(c->side));
-    if (c->snap_dst) std::memcpy(c->snap_dst, c->snap_host, c->snap_count * sizeof(float));
-    c->snap_pending = false;
+    // oldest first: snap_next is the set the next snapshot will take
+    for (int i = 0; i < 2; ++i) {
+        fdtd_ctx::Snap &sn = c->snap[(c->snap_next + i) & 1];
+        if (!sn.pending) continue;
+        if (sn.dst) std::memcpy(sn.dst, sn.host, sn.count * sizeof(float));
+        sn.pending = false;
+    }
     return 0;
 }
 
-const float *fdtd_snapshot_data(fdtd_ctx *c) { return c->snap_pending ? nullptr : c->snap_host; }
+const float *fdtd_snapshot_data(fdtd_ctx *c)
+{
+    if (c->snap_last < 0 || c->snap[c->snap_last].pending) return nullptr;
+    return c->snap[c->snap_last].host;
+}
 
 int fdtd_snapshot_async(fdtd_ctx *c, int field, float *dst, size_t count)
 {
     if (use_device(c)) return -10;
-    int rc = fdtd_snapshot_wait(c);
-    if (rc) return rc;
     FieldView v;
-    if ((rc = field_view(c, field, 0, &v))) return rc;
+    int rc = field_view(c, field, 0, &v);
+    if (rc) return rc;
     if (count != v.rows * c->nx) {
         set_error("fdtd_snapshot_async: count must be the number of cells of the slab");
         return -3;
     }
-    if (c->snap_count != count) {
-        if (c->snap_dev) (void)hipFree(c->snap_dev);
-        if (c->snap_host) (void)hipHostFree(c->snap_host);
-        c->snap_dev = nullptr;
-        c->snap_host = nullptr;
-        c->snap_count = 0;
-        HIPCHK(hipMalloc((void **)&c->snap_dev, count * sizeof(float)));
-        HIPCHK(hipHostMalloc((void **)&c->snap_host, count * sizeof(float), hipHostMallocDefault));
-        c->snap_count = count;
+    fdtd_ctx::Snap &sn = c->snap[c->snap_next];
+    if (sn.pending) {
+        // both staging sets are on their way: wait for the older one (this one)
+        if (c->snap_guard_at >= 0 && c->snap_guard == c->snap_next) c->snap_guard_at = -1;
+        HIPCHK(hipEventSynchronize(sn.done));
+        if (sn.dst) std::memcpy(sn.dst, sn.host, sn.count * sizeof(float));
+        sn.pending = false;
     }
-    // compact device copy on the compute stream (later steps may overwrite the
-    // field), then the slow D2H on the side stream
-    HIPCHK(hipMemcpy2DAsync(c->snap_dev, (size_t)c->nx * 4, v.ptr, (size_t)c->pitch * 4, (size_t)c->nx * 4, v.rows,
-                            hipMemcpyDeviceToDevice, c->stream));
+    if (sn.count != count) {
+        HIPCHK(hipStreamSynchronize(c->side));
+        if (sn.dev) (void)hipFree(sn.dev);
+        if (sn.host) (void)hipHostFree(sn.host);
+        sn.dev = nullptr;
+        sn.host = nullptr;
+        sn.count = 0;
+        HIPCHK(hipMalloc((void **)&sn.dev, count * sizeof(float)));
+        HIPCHK(hipHostMalloc((void **)&sn.host, count * sizeof(float), hipHostMallocDefault));
+        sn.count = count;
+    }
+    if (!sn.copied) {
+        HIPCHK(hipEventCreateWithFlags(&sn.copied, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&sn.done, hipEventDisableTiming));
+    }
+    // Side stream, behind the steps queued so far: a compact device copy, then the slow D2H.  The
+    // one-pass kernels write the arrays they do not read, so the next sweep leaves the source as
+    // it is and runs beside the device copy; the sweep after it waits for `copied`.  The split
+    // kernels update H in place: there the very next sweep waits.
     HIPCHK(hipEventRecord(c->snap_ev, c->stream));
     HIPCHK(hipStreamWaitEvent(c->side, c->snap_ev, 0));
-    HIPCHK(hipMemcpyAsync(c->snap_host, c->snap_dev, count * sizeof(float), hipMemcpyDeviceToHost, c->side));
-    c->snap_dst = dst;
-    c->snap_pending = true;
+    HIPCHK(hipMemcpy2DAsync(sn.dev, (size_t)c->nx * 4, v.ptr, (size_t)c->pitch * 4, (size_t)c->nx * 4, v.rows,
+                            hipMemcpyDeviceToDevice, c->side));
+    HIPCHK(hipEventRecord(sn.copied, c->side));
+    HIPCHK(hipMemcpyAsync(sn.host, sn.dev, count * sizeof(float), hipMemcpyDeviceToHost, c->side));
+    HIPCHK(hipEventRecord(sn.done, c->side));
+    if (c->snap_guard_at >= 0) {
+        // an earlier guard is still open: the main stream takes it now
+        HIPCHK(hipStreamWaitEvent(c->stream, c->snap[c->snap_guard].copied, 0));
+    }
+    c->snap_guard = c->snap_next;
+    c->snap_guard_at = c->launches + (c->one_pass() ? 1 : 0);
+    sn.dst = dst;
+    sn.pending = true;
+    c->snap_last = c->snap_next;
+    c->snap_next ^= 1;
     return 0;
 }
 
@@ -1136,13 +1428,19 @@ int fdtd_read_probes(fdtd_ctx *c, int64_t first_step, int nsteps, float *dst, si
         return -3;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
+    // the rows sit in a ring: one copy, two when the range wraps around its end
     const size_t row = (size_t)FDTD_MAX_PROBES * nf;
-    std::vector<float> tmp(row);
-    for (int s = 0; s < nsteps; ++s) {
-        const int slot = (int)((first_step + s) % c->probe_cap);
-        HIPCHK(hipMemcpy(tmp.data(), c->probe_ring + (size_t)slot * row, row * sizeof(float), hipMemcpyDeviceToHost));
-        std::memcpy(dst + (size_t)s * np * nf, tmp.data(), (size_t)np * nf * sizeof(float));
-    }
+    std::vector<float> tmp((size_t)nsteps * row);
+    const int first_slot = (int)(first_step % c->probe_cap);
+    const int n1 = std::min(nsteps, c->probe_cap - first_slot);
+    if (n1 > 0)
+        HIPCHK(hipMemcpy(tmp.data(), c->probe_ring + (size_t)first_slot * row, (size_t)n1 * row * sizeof(float),
+                         hipMemcpyDeviceToHost));
+    if (nsteps > n1)
+        HIPCHK(hipMemcpy(tmp.data() + (size_t)n1 * row, c->probe_ring, (size_t)(nsteps - n1) * row * sizeof(float),
+                         hipMemcpyDeviceToHost));
+    for (int s = 0; s < nsteps; ++s)
+        std::memcpy(dst + (size_t)s * np * nf, tmp.data() + (size_t)s * row, (size_t)np * nf * sizeof(float));
     return 0;
 }
 
@@ -1152,7 +1450,7 @@ size_t fdtd_halo_count(const fdtd_ctx *c)
     return c->is2d() ? (size_t)c->nx : (size_t)3 * c->nx * c->ny;
 }
 
-static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get)
+static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get, float *staging)
 {
     if (side < 0 || side > 1 || count != fdtd_halo_count(c)) {
         set_error("halo: bad side or count");
@@ -1162,12 +1460,22 @@ static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get)
     if (c->deep()) {
         int rc;
         if (get) {
-            if ((rc = deep_halo_kernel(c, 1 << side, false))) return rc;
-            HIPCHK(hipMemcpyAsync(host, c->halo_send[side], count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+            float *buf = staging;
+            if (!buf) {
+                if ((rc = ensure_deep_buffers(c))) return rc;
+                buf = c->halo_send[side];
+            }
+            if ((rc = deep_halo_kernel(c, 1 << side, false, buf, buf, c->stream))) return rc;
+            HIPCHK(hipMemcpyAsync(host, buf, count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
         } else {
             if ((rc = ensure_deep_buffers(c))) return rc;
             HIPCHK(hipMemcpyAsync(c->halo_recv[side], host, count * sizeof(float), hipMemcpyHostToDevice, c->stream));
-            if ((rc = deep_halo_kernel(c, 1 << side, true))) return rc;
+            if ((rc = deep_halo_kernel(c, 1 << side, true, c->halo_recv[side], c->halo_recv[side], c->stream)))
+                return rc;
+            // the neighbour's material codes travel with the rows: they decide the kernel variant
+            const size_t n = (size_t)c->tb_steps * c->nx;
+            c->halo_top[side] = top_code((const uint8_t *)(host + (size_t)6 * n), n);
+            c->ntab_halo = 1 + std::max(c->halo_top[0], c->halo_top[1]);
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         return 0;
@@ -1188,10 +1496,13 @@ static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get)
     return 0;
 }
 
-int fdtd_halo_get(fdtd_ctx *c, int side, float *dst, size_t count) { return halo_copy(c, side, dst, count, true); }
+int fdtd_halo_get(fdtd_ctx *c, int side, float *dst, size_t count)
+{
+    return halo_copy(c, side, dst, count, true, nullptr);
+}
 int fdtd_halo_put(fdtd_ctx *c, int side, const float *src, size_t count)
 {
-    return halo_copy(c, side, const_cast<float *>(src), count, false);
+    return halo_copy(c, side, const_cast<float *>(src), count, false, nullptr);
 }
 
 // ---- checkpoint ----------------------------------------------------------
@@ -1351,6 +1662,35 @@ int fdtd_comm_init(fdtd_ctx *c, const char id[128], int rank, int world)
     return comm_create(id, rank, world, &c->comm);
 }
 
+int fdtd_comm_local_group(int world, void **group)
+{
+    if (!group || world < 1) {
+        set_error("fdtd_comm_local_group: bad argument");
+        return -3;
+    }
+    *group = local_group_create(world);
+    return 0;
+}
+
+void fdtd_comm_local_group_free(void *group) { local_group_destroy((LocalGroup *)group); }
+
+int fdtd_comm_init_local(fdtd_ctx *c, void *group, int rank, int world)
+{
+    if (!group || world < 1 || rank < 0 || rank >= world) {
+        set_error("fdtd_comm_init_local: bad group, rank or world");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    if (c->comm) {
+        comm_destroy(c->comm);
+        c->comm = nullptr;
+    }
+    c->rank = rank;
+    c->world = world;
+    c->halo_stale = true;
+    return comm_create_local((LocalGroup *)group, rank, &c->comm);
+}
+
 int fdtd_comm_selftest(fdtd_ctx *c)
 {
     if (!c->comm) {
@@ -1361,7 +1701,8 @@ int fdtd_comm_selftest(fdtd_ctx *c)
     if (c->deep()) {
         // the packed boundary rows of side 0 -> the receive buffer of side 1, through ncclSend/ncclRecv
         const size_t n = c->deep_count();
-        int rc = deep_halo_kernel(c, 3, false);
+        int rc = ensure_deep_buffers(c);
+        if (!rc) rc = deep_halo_kernel(c, 3, false, c->halo_send[0], c->halo_send[1], c->stream);
         if (!rc) rc = comm_group_start(c->comm);
         if (!rc) rc = comm_send(c->comm, c->halo_send[0], n, c->rank, c->stream);
         if (!rc) rc = comm_recv(c->comm, c->halo_recv[1], n, c->rank, c->stream);

@@ -29,6 +29,17 @@ __device__ __forceinline__ float e_update(const MatEntry &m, float dt, float e0,
     return (float)((double)m.c * acc);
 }
 
+// The same with the three fp64 factors taken from the table (host_setup.cpp builds them with the
+// operations above).
+__device__ __forceinline__ float e_update_wide(const MatCoef &m, float e0, float e1, float d0, float d1, float d2)
+{
+    const float f = m.d * e0 - m.a * e1;
+    double acc = (double)f + m.k1 * (double)d0;
+    acc = acc - m.k2 * (double)d1;
+    acc = acc + m.k3 * (double)d2;
+    return (float)((double)m.c * acc);
+}
+
 // First-order Mur face value, fdtd_calculations.cu:240-248 and its siblings.
 // r_here: rp on the face layer, r_in: rp on the first interior layer.
 __device__ __forceinline__ float mur_face(float dt, float du, float mu0, float eps0, float r_here,

@@ -31,6 +31,10 @@ struct alignas(16) MatEntry {
     float a, c, d, tau;
 };
 
+// Rows of the wide coefficient table a workgroup of the multi-step sweep can hold in LDS next to
+// its parked rows (48 bytes each); grids whose highest material code is below take it.
+constexpr int kWideTableRows = 160;
+
 struct MaterialRow {
     float sigma, eps_s, eps_inf, tau_d;
 };
@@ -71,6 +75,7 @@ struct Sweep2D {
     MatEntry one;   // table[0], used when the grid holds a single material (ntab == 1)
     int ntab;
     int chunk_rows;
+    int row_begin, row_end; // local rows this launch covers (the fused sweep only)
     int variant;    // tuning switch: bit 0 = nontemporal hint on the last touch of re-read lines
     int band;       // block order: 0 = row-major, else rows per band (multiple of 8)
     int nopad;      // row-major order without padding the x block count to a multiple of 8
@@ -79,7 +84,8 @@ struct Sweep2D {
 
 // The multi-step 2-D sweep (sweep2d_tb.hip): K time steps in one pass over memory.
 constexpr int kMaxStepsPerPass = 8;     // one column of the two halo words on either side goes stale per step
-constexpr int kMaxStepsPerPassTable = 7; // grids with several materials: the table takes 4 KB of the LDS
+constexpr int kFastStepsPerPassTable = 7; // grids with several materials: the table takes 4 KB of the LDS, so at 8
+                                         // steps per pass a block has three waves instead of four
 constexpr int kDefaultStepsPerPass = 8; // 16384^2 vacuum: 4: 358, 5: 430, 6: 498, 7: 562, 8: 612 Gcell-updates/s
 constexpr int kTbOwnWords = 60; // 16-byte words of a row a wave owns
 constexpr int kTbHaloWords = 2; // words it holds on either side of them
@@ -93,6 +99,7 @@ struct SweepTB {
     float *dz_a, *dz_b;         //   rows of a wave are owned -- and overwritten -- by its neighbours)
     const uint8_t *code;
     const MatEntry *table;
+    const MatCoef *table_wide;            // the same rows with the three fp64 factors spelled out
     MatEntry one;
     int ntab;
     SourceList src;                       // src.jz is not used
@@ -103,12 +110,19 @@ struct SweepTB {
     float *ring;                          // probe ring, nullptr = no probes
     int slot[kMaxStepsPerPass];           // ring slots of the intermediate levels 1 .. K-1
     int rows;                             // owned rows per wave
-    int big_bands, tail_rows;             // bands of `rows` rows; the rows after them go in bands of tail_rows
+    // Rows this launch covers: big_bands bands of `rows` rows from y_begin on, then bands of
+    // tail_rows rows from tail_begin up to y_end (the rows between the two regions, if any, belong
+    // to another launch of the same pass).
+    int y_begin, y_end, tail_begin;
+    int big_bands, tail_rows;
     int strips;                           // waves across a row (kTbOwnWords owned words each)
+    int map;                              // 0: waves numbered band by band; 1: each XCD walks its own panel of strips
+    int strips_per_xcd;                   // map 1: ceil(strips / 8)
 };
 
 struct Mur2D {
     Grid2D g;
+    int j_begin, j_end; // local rows this launch finishes (x-face cells of those rows, y faces that lie in them)
     float *ez_t;       // level n+1
     const float *ez_s; // level n
     const float *rpx0, *rpxe, *rpy0, *rpye; // global layouts of fdtd.cu:952-977
@@ -140,6 +154,7 @@ struct Sweep3D {
 
 struct Mur3D {
     Grid3D g;
+    int k_begin, k_end; // local planes this launch finishes
     float *e_t[3];
     const float *e_s[3];
     const float *rp[6];
@@ -162,6 +177,7 @@ struct Fused3D {
     int ntab;
     int nsrc;
     float jz;
+    int k_begin, k_end;                    // local planes this launch covers
     long long plane_words;                 // 16-byte words of one plane: ny * pitch / 4
     int seg_words;                         // words of one XCD's segment of a plane (plane_words / 8, rounded up)
     int seg_blocks;                        // 256-thread blocks per segment
@@ -203,7 +219,8 @@ struct Probe3D {
 void launch_h2d(const Sweep2D &a, void *stream);
 void launch_de2d(const Sweep2D &a, void *stream);
 void launch_sweep2d(const Sweep2D &a, void *stream);
-void launch_sweep2d_tb(const SweepTB &a, int steps, void *stream);
+// Returns 0, or -1 when no kernel exists for `steps`.
+int launch_sweep2d_tb(const SweepTB &a, int steps, void *stream);
 const char *sweep2d_tb_kernel_name();
 void launch_sweep3d(const Fused3D &a, void *stream);
 void launch_mur2d(const Mur2D &a, void *stream);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void fdtd2d_mur(const Mur2D a)
     if (t < 2L * g.nyl) {
         const int side = (int)(t / g.nyl), j = (int)(t % g.nyl);
         const int y = g.gy0 + j;
-        if (y < 1 || y > g.gny - 2) return;
+        if (y < 1 || y > g.gny - 2 || j < a.j_begin || j >= a.j_end) return;
         const size_t row = (size_t)(j + 1) * pitch;
         if (side == 0) {
             const size_t f = row, in = row + 1;
@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void fdtd2d_mur(const Mur2D a)
     const int side = (int)(t / g.nx), x = (int)(t % g.nx);
     if (x < 1 || x > g.nx - 2) return;
     if (side == 0) {
-        if (g.gy0 != 0) return;
+        if (g.gy0 != 0 || a.j_begin > 0 || a.j_end < 1) return;
         const size_t f = pitch + x, in = 2 * pitch + x;
         a.ez_t[f] = mur_face(a.dt, a.dy, a.mu0, a.eps0, a.rpy0[x], a.rpy0[g.nx + x], a.ez_t[in], a.ez_s[in],
                              a.ez_s[f]);
     } else {
-        if (g.gy0 + g.nyl != g.gny) return;
+        if (g.gy0 + g.nyl != g.gny || a.j_begin > g.nyl - 1 || a.j_end < g.nyl) return;
         const size_t f = (size_t)g.nyl * pitch + x, in = (size_t)(g.nyl - 1) * pitch + x;
         a.ez_t[f] = mur_face(a.dt, a.dy, a.mu0, a.eps0, a.rpye[g.nx + x], a.rpye[x], a.ez_t[in], a.ez_s[in],
                              a.ez_s[f]);
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void fdtd3d_mur(const Mur3D a)
         const size_t ri = ((size_t)z * g.ny + y) * 2;
         const float r_here = side ? rp[ri + 1] : rp[ri], r_in = side ? rp[ri] : rp[ri + 1];
         const size_t f = base + (side ? g.nx - 1 : 0), in = base + (side ? g.nx - 2 : 1);
+        if (k < a.k_begin || k >= a.k_end) return;
         if (y <= g.ny - 2 && z >= 1 && z <= g.gnz - 2) {
             // the high face takes eySource for both interior terms (:323, :325)
             const float et_in = side ? eys[in] : eyt[in];
@@ -230,6 +231,7 @@ __global__ __launch_bounds__(256) void fdtd3d_mur(const Mur3D a)
         const float r_here = side ? rp[ri + g.nx] : rp[ri], r_in = side ? rp[ri] : rp[ri + g.nx];
         const size_t f = base + (side ? (size_t)(g.ny - 1) * rs : 0);
         const size_t in = base + (side ? (size_t)(g.ny - 2) * rs : rs);
+        if (k < a.k_begin || k >= a.k_end) return;
         if (x <= g.nx - 2 && z >= 1 && z <= g.gnz - 2)
             ext[f] = mur_face(dt, a.dy, mu0, eps0, r_here, r_in, ext[in], exs[in], exs[f]);
         if (x >= 1 && x <= g.nx - 2 && z <= g.gnz - 2)
@@ -243,6 +245,7 @@ __global__ __launch_bounds__(256) void fdtd3d_mur(const Mur3D a)
         const int y = (int)(r / g.nx), x = (int)(r % g.nx);
         if (side == 0 ? g.gz0 != 0 : g.gz0 + g.nzl != g.gnz) return;
         const int k = side ? g.nzl - 1 : 0, kin = side ? g.nzl - 2 : 1;
+        if (k < a.k_begin || k >= a.k_end) return;
         const float *rp = side ? a.rp[FDTD_RP_ZEND] : a.rp[FDTD_RP_Z0];
         const size_t ri = (size_t)y * g.nx + x, rl = (size_t)g.ny * g.nx;
         const float r_here = side ? rp[ri + rl] : rp[ri], r_in = side ? rp[ri] : rp[ri + rl];

@@ -103,8 +103,8 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const Block
     if (xw0 >= g.nx) return;
     const int x4 = xw0 + lane * 4;
     const bool act = x4 < g.nx;
-    const int j0 = chunk * a.chunk_rows;
-    const int j1 = min(j0 + a.chunk_rows, g.nyl);
+    const int j0 = a.row_begin + chunk * a.chunk_rows;
+    const int j1 = min(j0 + a.chunk_rows, a.row_end);
     const size_t pitch = (size_t)g.pitch;
 
     // x guards of the four columns held by this lane
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const Block
 void launch_sweep2d(const Sweep2D &a, void *stream)
 {
     BlockMap xblocks;
-    xblocks.chunks = (a.g.nyl + a.chunk_rows - 1) / a.chunk_rows;
+    if (a.row_end <= a.row_begin) return;
+    xblocks.chunks = (a.row_end - a.row_begin + a.chunk_rows - 1) / a.chunk_rows;
     xblocks.xblocks = (a.g.nx + 1023) / 1024;
     xblocks.xpad = a.nopad ? xblocks.xblocks : (xblocks.xblocks + 7) / 8 * 8;
     xblocks.band = a.band;

@@ -15,8 +15,10 @@
 // need -- 62 owned words cost 6 %) of `rows` consecutive rows; lanes 0-1 and
 // 62-63 hold the words to the left and right of them, whose level-s values are
 // only valid in the 8 - s columns next to the owned words (one column is lost
-// per step, hence K <= 8; registers and LDS are full at K = 8 too).  The wave
-// marches upwards; in iteration j stage s works on row j - (s - 1), so the
+// per step, hence K <= 8; registers and LDS are full at K = 8 too).  A launch
+// covers a range of rows (a pass may be split into a launch for the rows next
+// to the slab edges and one for the rest, so that the halo exchange of the
+// former overlaps the latter).  The wave marches upwards; in iteration j stage s works on row j - (s - 1), so the
 // pipeline is primed K rows below the first owned row and drained K - 1 rows
 // above the last: rows outside the owned window are recomputed, not
 // communicated.  Because neighbouring waves re-read the rows a wave writes, the
@@ -33,6 +35,7 @@
 // right after the E update of the row, the y = 0 row one iteration later (it
 // needs the new row 1), the y = ny-1 row from the carried row ny-2.  Level K is
 // stored as the E update leaves it; the ordinary Mur kernel finishes it.
+#include <cstdlib>
 #include <type_traits>
 
 #include "device_math.h"
@@ -53,29 +56,56 @@ struct StageOut {
     f4 ez, hx, hy, dz;
 };
 
+// Waves per workgroup: four, except for the table variant at K = 8, whose 20 KB of parked rows per
+// wave plus the 4 KB table allow three (two workgroups per CU either way).
+template <int K, bool ONE> constexpr int tb_waves() { return (!ONE && K >= 8) ? 3 : 4; }
+
 // At least two waves per SIMD (the register allocator otherwise settles for one at some K).
-template <int K, bool ONE>
-__global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
+// PLAIN: loads without the nontemporal hint (the default).
+// WIDE (table variant): rows of 48 bytes that spell out the three fp64 factors of the E update,
+// which the 16-byte rows make every cell rebuild from dt and tau (7 fp64 instructions per cell
+// and stage); at most kWideTableRows material codes.
+template <int K, bool ONE, bool PLAIN, bool WIDE>
+__global__ __launch_bounds__((tb_waves<K, ONE>() * 64), 2) void fdtd2d_sweep_tb(const SweepTB a)
 {
-    constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords;
-    // Grids with several materials: the coefficient table (256 rows of 16 bytes) sits in LDS, where a
-    // lookup per cell and stage costs a fraction of a cached global load.
-    __shared__ MatEntry tab[ONE ? 1 : FDTD_MAX_CODES];
+    constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords, WPB = tb_waves<K, ONE>();
+    // Grids with several materials: the coefficient table sits in LDS, where a lookup per cell and
+    // stage costs a fraction of a cached global load.
+    __shared__ MatEntry tab[(ONE || WIDE) ? 1 : FDTD_MAX_CODES];
+    __shared__ MatCoef tabw[(!ONE && WIDE) ? kWideTableRows : 1];
     if (!ONE) {
-        tab[threadIdx.x] = a.table[threadIdx.x];
+        if (WIDE) {
+            const f4 *src = (const f4 *)a.table_wide;
+            f4 *dst = (f4 *)tabw;
+            for (int i = threadIdx.x; i < kWideTableRows * 3; i += WPB * 64) dst[i] = src[i];
+        } else {
+            for (int i = threadIdx.x; i < FDTD_MAX_CODES; i += WPB * 64) tab[i] = a.table[i];
+        }
         __syncthreads(); // before any wave leaves
     }
     const Grid2D &g = a.g;
     const int lane = threadIdx.x & 63;
-    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int strip = (int)(wv % a.strips);
+    int strip, band;
+    if (a.map == 0) {
+        const long wv = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+        strip = (int)(wv % a.strips);
+        band = (int)(wv / a.strips);
+    } else {
+        // Block ids are dealt to the 8 XCDs in turn: XCD i (block id mod 8) walks panel i, a run of
+        // strips_per_xcd adjacent strips, band after band, so the lines two adjacent strips share are
+        // fetched by one L2.  (Placement is the hardware's habit, not a promise: it only affects speed.)
+        const unsigned xcd = blockIdx.x & 7u;
+        const long q = (long)(blockIdx.x >> 3) * WPB + (threadIdx.x >> 6);
+        band = (int)(q / a.strips_per_xcd);
+        strip = (int)xcd * a.strips_per_xcd + (int)(q % a.strips_per_xcd);
+        if (strip >= a.strips) return;
+    }
     // The first big_bands bands hold `rows` rows each, the bands after them tail_rows: short waves
     // at the end of the launch keep the GPU full while the last long ones finish (3 % at 16384^2).
-    const int band = (int)(wv / a.strips);
     const bool big = band < a.big_bands;
-    const int y0 = big ? band * a.rows : a.big_bands * a.rows + (band - a.big_bands) * a.tail_rows;
-    if (y0 >= g.nyl) return;
-    const int y1 = min(y0 + (big ? a.rows : a.tail_rows), g.nyl);
+    const int y0 = big ? a.y_begin + band * a.rows : a.tail_begin + (band - a.big_bands) * a.tail_rows;
+    if (y0 >= a.y_end) return;
+    const int y1 = min(y0 + (big ? a.rows : a.tail_rows), a.y_end);
     const int w = strip * OWN - LEFT + lane; // word of the row held by this lane
     const int x4 = w * 4;
     const bool act = w >= 0 && x4 < g.nx;
@@ -119,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
     // (K = 8: 21 slots per wave would leave room for one block per CU only; the hy of its last
     // stage stays in registers instead.)
     constexpr bool HY_LAST_IN_REGS = K >= 8;
-    __shared__ f4 parked[4][K > 1 ? 3 * (K - 1) - (HY_LAST_IN_REGS ? 1 : 0) : 1][64];
+    __shared__ f4 parked[WPB][K > 1 ? 3 * (K - 1) - (HY_LAST_IN_REGS ? 1 : 0) : 1][64];
     f4(*park_w)[64] = parked[threadIdx.x >> 6];
     auto park = [&](int stage_index, int which) -> f4 & { return park_w[3 * stage_index + which][lane]; };
 
@@ -138,8 +168,14 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
         // the four table rows of this lane's cells first: the E update at the end of the stage needs
         // them, and the H and D arithmetic in between covers the LDS latency
         MatEntry m[4];
+        MatCoef mw[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) m[i] = ONE ? a.one : tab[(in.cd >> (8 * i)) & 0xffu];
+        for (int i = 0; i < 4; ++i) {
+            if (!ONE && WIDE)
+                mw[i] = tabw[(in.cd >> (8 * i)) & 0xffu];
+            else
+                m[i] = ONE ? a.one : tab[(in.cd >> (8 * i)) & 0xffu];
+        }
         const float e_right = __shfl_down(in.ez.x, 1);
         const float er[4] = {in.ez.y, in.ez.z, in.ez.w, e_right};
 #pragma unroll
@@ -167,8 +203,9 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
-                                                 : ezp[i];
+            o.ez[i] = !(IN || (gy_ez && m_ez[i])) ? ezp[i]
+                      : (!ONE && WIDE)             ? e_update_wide(mw[i], in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                                                   : e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
         return o;
     };
 
@@ -224,16 +261,17 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
         f4 hx, hy, ezp, dz, dzp, ezu;
         unsigned cd;
     };
+    auto ld4 = [&](const float *p) -> f4 { return PLAIN ? *(const f4 *)p : ld4_stream(p); };
     auto load = [&](auto inner, RowIn &r, int j) {
         const bool ld = decltype(inner)::value || act;
         const long off = (long)(j + 1) * pitch + x4;
-        r.hx = ld ? ld4_stream(a.hx_r + off) : zero;
-        r.hy = ld ? ld4_stream(a.hy_r + off) : zero;
-        r.ezp = ld ? ld4_stream(a.ez_p + off) : zero;
-        r.dz = ld ? ld4_stream(a.dz_n + off) : zero;
-        r.dzp = ld ? ld4_stream(a.dz_p + off) : zero;
-        r.ezu = ld ? ld4_stream(a.ez_n + off + pitch) : zero;
-        r.cd = ld ? *(const unsigned *)(a.code + off) : 0u;
+        r.hx = ld ? ld4(a.hx_r + off) : zero;
+        r.hy = ld ? ld4(a.hy_r + off) : zero;
+        r.ezp = ld ? ld4(a.ez_p + off) : zero;
+        r.dz = ld ? ld4(a.dz_n + off) : zero;
+        r.dzp = ld ? ld4(a.dz_p + off) : zero;
+        r.ezu = ld ? ld4(a.ez_n + off + pitch) : zero;
+        r.cd = (!ONE && ld) ? *(const unsigned *)(a.code + off) : 0u; // a single material: no code is looked at
     };
 
     auto march = [&](auto inner) {
@@ -251,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
     }
     RowIn cur;
     load(inner, cur, jlo);
-    f4 ezc = (IN || act) ? ld4_stream(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
+    f4 ezc = (IN || act) ? ld4(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
 
     for (int j = jlo; j <= jhi; ++j) {
         RowIn nxt;
@@ -343,31 +381,50 @@ __global__ __launch_bounds__(256, 2) void fdtd2d_sweep_tb(const SweepTB a)
         march(std::false_type{});
 }
 
-template <int K> void launch_k(const SweepTB &a, hipStream_t stream)
+template <int K> int launch_k(const SweepTB &a, hipStream_t stream)
 {
-    const long done = (long)a.big_bands * a.rows;
-    const long bands = a.big_bands + (done < a.g.nyl ? (a.g.nyl - done + a.tail_rows - 1) / a.tail_rows : 0);
-    const long waves = bands * a.strips;
-    const dim3 grid((unsigned)((waves + 3) / 4));
-    if (a.ntab == 1)
-        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true>), grid, dim3(256), 0, stream, a);
-    else if constexpr (K <= kMaxStepsPerPassTable)
-        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false>), grid, dim3(256), 0, stream, a);
+    const long tail = a.tail_begin < a.y_end ? (a.y_end - a.tail_begin + a.tail_rows - 1) / a.tail_rows : 0;
+    const long bands = a.big_bands + tail;
+    if (bands <= 0) return 0;
+    const bool one = a.ntab == 1;
+    const long wpb = one ? tb_waves<K, true>() : tb_waves<K, false>();
+    long blocks;
+    if (a.map == 0)
+        blocks = (bands * a.strips + wpb - 1) / wpb;
+    else
+        blocks = 8 * ((bands * a.strips_per_xcd + wpb - 1) / wpb);
+    const dim3 grid((unsigned)blocks), block((unsigned)(wpb * 64));
+    // Loads without the nontemporal hint: the lines two adjacent waves share stay in L2 for the
+    // second of them (16384^2, K = 8: 3.32 ms per pass against 3.42 with the hint).  The hinted
+    // form is kept for K = 8 on a single material as a tuning reference (FDTD_TB_PLAIN_LOADS=0).
+    static const bool hinted = std::getenv("FDTD_TB_PLAIN_LOADS") && !std::atoi(std::getenv("FDTD_TB_PLAIN_LOADS"));
+    static const bool narrow = std::getenv("FDTD_TB_NARROW_TABLE") && std::atoi(std::getenv("FDTD_TB_NARROW_TABLE"));
+    if (one) {
+        if (K == 8 && hinted)
+            hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, K != 8, false>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, true, false>), grid, block, 0, stream, a);
+    } else if (a.ntab <= kWideTableRows && !narrow) {
+        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, true>), grid, block, 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, false>), grid, block, 0, stream, a);
+    }
+    return 0;
 }
 
 } // namespace
 
-void launch_sweep2d_tb(const SweepTB &a, int steps, void *stream)
+int launch_sweep2d_tb(const SweepTB &a, int steps, void *stream)
 {
     switch (steps) {
-    case 2: launch_k<2>(a, (hipStream_t)stream); break;
-    case 3: launch_k<3>(a, (hipStream_t)stream); break;
-    case 4: launch_k<4>(a, (hipStream_t)stream); break;
-    case 5: launch_k<5>(a, (hipStream_t)stream); break;
-    case 6: launch_k<6>(a, (hipStream_t)stream); break;
-    case 7: launch_k<7>(a, (hipStream_t)stream); break;
-    case 8: launch_k<8>(a, (hipStream_t)stream); break;
-    default: launch_k<1>(a, (hipStream_t)stream); break;
+    case 2: return launch_k<2>(a, (hipStream_t)stream);
+    case 3: return launch_k<3>(a, (hipStream_t)stream);
+    case 4: return launch_k<4>(a, (hipStream_t)stream);
+    case 5: return launch_k<5>(a, (hipStream_t)stream);
+    case 6: return launch_k<6>(a, (hipStream_t)stream);
+    case 7: return launch_k<7>(a, (hipStream_t)stream);
+    case 8: return launch_k<8>(a, (hipStream_t)stream);
+    default: return -1; // a single step is the one-step sweep's job
     }
 }
 

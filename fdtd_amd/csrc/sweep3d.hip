@@ -61,13 +61,13 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
     // lines of plane z-1 and z+1 it needs are the ones it pulled into its own L2 a plane ago.
     const int p4 = g.pitch >> 2;
     const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
-    const int k = (int)(seq / (unsigned)a.seg_blocks);
+    const int k = a.k_begin + (int)(seq / (unsigned)a.seg_blocks);
     const unsigned in_seg = (seq % (unsigned)a.seg_blocks) * 256u + threadIdx.x;
     const unsigned in_plane = xcd * (unsigned)a.seg_words + in_seg;      // word within the plane
     const int y = (int)(in_plane / (unsigned)p4);
     const int x4 = (int)(in_plane % (unsigned)p4) * 4;
     const long long t = (long long)k * a.plane_words + in_plane;
-    const bool act = in_seg < (unsigned)a.seg_words && in_plane < (unsigned)a.plane_words && k < g.nzl && x4 < g.nx;
+    const bool act = in_seg < (unsigned)a.seg_words && in_plane < (unsigned)a.plane_words && k < a.k_end && x4 < g.nx;
     const int z = g.gz0 + k;
     const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
     const size_t o = act ? (size_t)(k + 1) * ps + (size_t)y * rs + x4 : ps;
@@ -232,7 +232,8 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
 
 void launch_sweep3d(const Fused3D &a, void *stream)
 {
-    const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)a.g.nzl);
+    if (a.k_end <= a.k_begin) return;
+    const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)(a.k_end - a.k_begin));
     static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 2;
 #define GO(W)                                                                                     \
     do {                                                                                          \

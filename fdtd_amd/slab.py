@@ -44,8 +44,18 @@ class SlabRunner:
         # An engine that advances several steps per pass over memory keeps halos that deep (every
         # live array, material codes included) and recomputes the rows in them: it exchanges once
         # per pass, and once before the first pass so that the halos hold the neighbours' state.
-        self.stride = int(getattr(engine, "steps_per_pass", 1))
-        self.primed = self.stride == 1
+        self.primed = False
+
+    @property
+    def stride(self):
+        """Steps between two exchanges, asked of the engine every time (it may change when
+        materials are loaded)."""
+        return int(getattr(self.engine, "steps_per_pass", 1))
+
+    def invalidate(self):
+        """Call after anything that changes the engine's state behind the stepper's back (fields,
+        material codes, a checkpoint): the next step() exchanges first."""
+        self.primed = False
 
     def exchange(self):
         """Host-staged halo exchange with ranks rank-1 and rank+1."""

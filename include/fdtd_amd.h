@@ -57,8 +57,10 @@ enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
  * the same arithmetic per cell and step, 16 more bytes of HBM per cell (E and D
  * keep four arrays instead of two).  fdtd_step(n) runs n / steps_per_pass
  * passes and the remainder as one shorter pass (a single step: FUSED).
- * AUTO: MULTISTEP in 2-D when its arrays fit into the free device memory,
- * else FUSED. */
+ * AUTO: MULTISTEP for 2-D grids of 6 M cells or more (extents of the WHOLE
+ * grid, so every slab of it decides alike), else FUSED; a whole grid whose
+ * MULTISTEP arrays do not fit into device memory falls back to FUSED, a slab
+ * reports the error. */
 enum { FDTD_KERNEL_AUTO = 0, FDTD_KERNEL_SPLIT = 1, FDTD_KERNEL_FUSED = 2, FDTD_KERNEL_MULTISTEP = 3 };
 
 typedef struct fdtd_options {
@@ -69,7 +71,8 @@ typedef struct fdtd_options {
     int32_t slab_begin;  /* first global row of the slab axis held here (y in 2-D, z in 3-D) */
     int32_t slab_count;  /* rows held; 0 = the whole grid */
     int32_t chunk_rows;  /* rows marched by one workgroup of the fused sweep; 0 = default */
-    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (8; 7 at most once several materials are on the grid) */
+    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (8, 6 below 48 M cells; a whole grid drops to
+                             * 7 once several materials are on it, a slab or an explicit value never changes) */
     int32_t reserved[8];
 } fdtd_options;
 
@@ -163,6 +166,15 @@ int fdtd_steps_per_pass(const fdtd_ctx *ctx);
  * returns the milliseconds of up to `capacity` steps. */
 int fdtd_profile_begin(fdtd_ctx *ctx, int capacity);
 int fdtd_profile_read(fdtd_ctx *ctx, float *sweep_ms, int capacity, int *count);
+/* The same, and steps[i] = the time steps launch i advanced (1 for the one-step
+ * kernels; a pass of the multi-step sweep advances up to steps_per_pass, the
+ * remainder pass of an fdtd_step() call fewer). */
+int fdtd_profile_read_launches(fdtd_ctx *ctx, float *sweep_ms, int32_t *steps, int capacity, int *count);
+/* Shape of one launch of the main sweep over the slab: the waves it starts and
+ * the row iterations they execute in all (a wave of the multi-step sweep
+ * marches its rows plus 2 * steps_per_pass - 1 rows around them; the one-step
+ * kernels handle one row per wave).  Input of issue-rate estimates. */
+int fdtd_sweep_work(const fdtd_ctx *ctx, int64_t *waves, int64_t *row_iterations);
 /* Name of the kernel that does the main sweep (as a profiler reports it). */
 const char *fdtd_sweep_kernel_name(const fdtd_ctx *ctx);
 
@@ -223,10 +235,25 @@ int fdtd_halo_put(fdtd_ctx *ctx, int side, const float *src, size_t count);
 
 /* RCCL form of the exchange: rank 0 creates an id (128 bytes), every rank
  * passes it to fdtd_comm_init(); afterwards fdtd_step() exchanges halos with
- * ranks rank-1 and rank+1 after every step (ncclSend/ncclRecv in one group)
- * on the context's stream.  The slab of rank r must be the r-th slab. */
+ * ranks rank-1 and rank+1 after every step (every pass of the multi-step
+ * mode), ncclSend/ncclRecv in one group.  The rows next to a neighbour are
+ * swept first on a second stream and the exchange follows them there while the
+ * main stream sweeps the interior.  The slab of rank r must be the r-th slab.
+ * Calls that change the state behind the stepper's back (fdtd_set_codes,
+ * fdtd_load_materials, fdtd_write_field, fdtd_checkpoint_load, fdtd_comm_init)
+ * make the next fdtd_step() of the multi-step mode start with an extra
+ * exchange: every rank must make them between the same two fdtd_step() calls. */
 int fdtd_comm_unique_id(char id[128]);
 int fdtd_comm_init(fdtd_ctx *ctx, const char id[128], int rank, int world);
+/* The same exchange between contexts of ONE process (no counterpart in the
+ * reference, no RCCL): each rank is a context driven by its own host thread,
+ * on one GPU or on several; messages are device-to-device copies after a
+ * rendezvous of the two threads.  fdtd_comm_local_group() creates the shared rendezvous object for
+ * `world` ranks, every rank passes it to fdtd_comm_init_local(); free it after
+ * the contexts are destroyed. */
+int fdtd_comm_local_group(int world, void **group);
+void fdtd_comm_local_group_free(void *group);
+int fdtd_comm_init_local(fdtd_ctx *ctx, void *group, int rank, int world);
 /* Diagnostic: sends the first owned ez row (3-D: ez plane) to this very rank
  * through ncclSend/ncclRecv into the upper halo and checks that it arrived.
  * Usable with a one-rank communicator; overwrites the upper halo. */

@@ -113,3 +113,18 @@ def run_and_compare(s, o, steps, check_every, where=""):
         done += n
         notbit += compare(s, o, peak, f"{where} step {done}")
     return notbit
+
+
+def assert_bits_equal(got, want, what=""):
+    """Bit identity with a readable report: how many cells differ, and in which rows / planes."""
+    got, want = np.asarray(got), np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    bad = got.view(np.uint32) != want.view(np.uint32)
+    if bad.any():
+        idx = np.argwhere(bad)
+        rows = sorted(set(int(i[-2]) for i in idx))
+        planes = sorted(set(int(i[0]) for i in idx))
+        first = tuple(int(v) for v in idx[0])
+        raise AssertionError(f"{what}: {int(bad.sum())} of {bad.size} cells differ; planes {planes[:8]}, rows "
+                             f"{rows[:12]}{'...' if len(rows) > 12 else ''} (last {rows[-1]}); first at {first}: "
+                             f"got {got[first]!r}, want {want[first]!r}")

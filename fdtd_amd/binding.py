@@ -91,6 +91,7 @@ SYMBOLS = [
     ("fdtd_halo_count", _SZ, [_VP]),
     ("fdtd_halo_get", _I, [_VP, _I, _VP, _SZ]),
     ("fdtd_halo_put", _I, [_VP, _I, _VP, _SZ]),
+    ("fdtd_halo_get_noalloc", _I, [_VP, _I, _VP, _SZ]),
     ("fdtd_comm_unique_id", _I, [C.c_char_p]),
     ("fdtd_comm_init", _I, [_VP, C.c_char_p, _I, _I]),
     ("fdtd_comm_local_group", _I, [_I, C.POINTER(_VP)]),
@@ -342,6 +343,11 @@ class Solver:
     def halo_get(self, side):
         out = np.empty(self.halo_count, dtype=np.float32)
         _check(self.lib.fdtd_halo_get(self._ctx, side, out.ctypes.data, out.size))
+        return out
+
+    def halo_get_noalloc(self, side):
+        out = np.empty(self.halo_count, dtype=np.float32)
+        _check(self.lib.fdtd_halo_get_noalloc(self._ctx, side, out.ctypes.data, out.size))
         return out
 
     def halo_put(self, side, data):

@@ -37,6 +37,31 @@ using namespace fdtd;
 namespace {
 constexpr size_t kSlack = 256; // floats (or bytes) of zero padding around each array
 
+// Staging memory of fdtd_halo_get_noalloc(): lives in the code object, so the entry point never
+// allocates.  Every GPU the library runs on holds its own copy (4 MiB) at its own address; the
+// name below is only a handle for hipGetSymbolAddress -- host code uses the per-device pointers.
+constexpr size_t kScratchFloats = (size_t)1 << 20;
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) float scratch[kScratchFloats];
+float *g_scratch[kMaxDevices] = {};
+
+// Once per device, with that device current.
+int scratch_init(int device)
+{
+    if (device < 0 || device >= kMaxDevices) {
+        set_error("device ordinal out of range");
+        return -3;
+    }
+    if (g_scratch[device]) return 0;
+    float *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr) {
+        set_error(std::string("hipGetSymbolAddress(scratch): ") + hipGetErrorString(e));
+        return -10;
+    }
+    g_scratch[device] = ptr;
+    return 0;
+}
 }
 
 struct fdtd_ctx {
@@ -929,6 +954,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
 
     c->device = opt->device;
     HIPCHK(hipSetDevice(c->device));
+    if (int rc = scratch_init(c->device)) return rc;
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     {
@@ -1500,6 +1526,27 @@ int fdtd_halo_get(fdtd_ctx *c, int side, float *dst, size_t count)
 {
     return halo_copy(c, side, dst, count, true, nullptr);
 }
+int fdtd_halo_get_noalloc(fdtd_ctx *c, int side, float *dst, size_t count)
+{
+    if (count > kScratchFloats) {
+        set_error("fdtd_halo_get_noalloc: the block exceeds the 4 MiB (1048576 floats) of built-in staging memory; "
+                  "use fdtd_halo_get");
+        return -3;
+    }
+    if (use_device(c)) return -10;
+    float *stage = g_scratch[c->device];
+    if (!stage) {
+        set_error("fdtd_halo_get_noalloc: no staging memory on this device");
+        return -10;
+    }
+    if (c->deep() && count > 0) {
+        // the last float holds the tail of the code bytes and may be written in part only; the
+        // array keeps what the previous call (of any context on this GPU) left there
+        HIPCHK(hipMemsetAsync(stage + count - 1, 0, sizeof(float), c->stream));
+    }
+    return halo_copy(c, side, dst, count, true, stage);
+}
+
 int fdtd_halo_put(fdtd_ctx *c, int side, const float *src, size_t count)
 {
     return halo_copy(c, side, const_cast<float *>(src), count, false, nullptr);

@@ -232,6 +232,15 @@ int fdtd_checkpoint_load(fdtd_ctx *ctx, const char *path);
 size_t fdtd_halo_count(const fdtd_ctx *ctx);
 int fdtd_halo_get(fdtd_ctx *ctx, int side, float *dst, size_t count);
 int fdtd_halo_put(fdtd_ctx *ctx, int side, const float *src, size_t count);
+/* No counterpart in the reference.  For callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc): fdtd_halo_get() with the packed block of the multi-step
+ * mode staged in a 4 MiB array that is part of the library's code object
+ * instead of buffers allocated on first use.  Same arguments and result as
+ * fdtd_halo_get(); fails when count exceeds 1048576 floats.  The array is one
+ * per GPU and shared by every context on it: two calls that overlap on one GPU
+ * race. */
+int fdtd_halo_get_noalloc(fdtd_ctx *ctx, int side, float *dst, size_t count);
 
 /* RCCL form of the exchange: rank 0 creates an id (128 bytes), every rank
  * passes it to fdtd_comm_init(); afterwards fdtd_step() exchanges halos with

@@ -133,6 +133,9 @@ def main():
                     help="N > 1: if RCCL cannot initialise, run with halos staged through the host (flagged in the output) "
                          "instead of failing")
     ap.add_argument("--no-one-step-leg", action="store_true", help="skip the extra one-step-sweep measurement")
+    ap.add_argument("--tissue", type=int, default=0, metavar="U",
+                    help="config 3: the 265x490 body slice data/pgmdata/v1_00800.pgm upsampled U times (32: 8480x15680), "
+                         "mat_specs_riken tissues, Mur with the default rp, source in the air beside the body (1 GPU)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --ny (or --nz) is the extent of the WHOLE grid, cut into --gpus slabs")
     args = ap.parse_args()
@@ -163,6 +166,10 @@ def main():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     is3d = args.nz > 1
+    if args.tissue:
+        if world > 1 or is3d:
+            raise SystemExit("--tissue is a one-GPU 2-D workload")
+        args.nx, args.ny = 265 * args.tissue, 490 * args.tissue
     nx = args.nx
     if args.strong:
         if (args.nz if is3d else args.ny) % world:
@@ -180,7 +187,7 @@ def main():
     else:
         gdims = (nx, args.ny * world, 1)
         slab = (rank * args.ny, args.ny)
-        src = [(nx // 2, gdims[1] // 2, 0)]
+        src = [(40 * args.tissue, 245 * args.tissue, 0)] if args.tissue else [(nx // 2, gdims[1] // 2, 0)]
         cells_per_rank = nx * args.ny
         bytes_per_cell = BYTES_PER_CELL_2D
     params = fdtd_amd.make_params(*gdims, src)
@@ -195,6 +202,10 @@ def main():
     solver = fdtd_amd.Solver(params, ecoef=B.ECOEF_CONSISTENT, kernel=kernel, device=local_rank,
                              slab=slab if world > 1 else None, chunk_rows=args.chunk_rows,
                              steps_per_pass=args.steps_per_pass)
+    if args.tissue:
+        data = os.path.join(ROOT, "data")
+        solver.load_materials(os.path.join(data, "mat_specs_riken"), os.path.join(data, "pgmdata"), first_slice=800,
+                              upsample=args.tissue)
     spp = solver.steps_per_pass          # time steps one full launch of the sweep advances
     halo = "none"
     halo_fallback = False
@@ -283,7 +294,8 @@ def main():
         value = total_cells * args.steps / elapsed / 1e6
         kernel_name = solver.sweep_kernel_name
         workload = (f"{gdims[0]}x{gdims[1]}x{gdims[2]} 3-D" if is3d else f"{gdims[0]}x{gdims[1]} 2-D TMz") + \
-            " vacuum + centre point source"
+            (f" tissue map (v1_00800.pgm x{args.tissue}, mat_specs_riken) + Mur + point source" if args.tissue
+             else " vacuum + centre point source")
         # Launches of the main sweep inside the timed region, grouped by the time steps they advanced:
         # fdtd_step(n) runs full passes and one shorter remainder pass (a single step: the one-step sweep).
         groups = {}
@@ -355,7 +367,7 @@ def main():
             issue = issue_bound(solver, full_k, sweep_avg_ms)
             if issue:
                 out["roofline"]["issue_bound"] = issue
-        if world == 1 and not is3d and not args.no_one_step_leg and kernel_name != "fdtd2d_sweep":
+        if world == 1 and not is3d and not args.no_one_step_leg and not args.tissue and kernel_name != "fdtd2d_sweep":
             solver.close()
             out["roofline_one_step"] = one_step_leg(params, local_rank, cells_per_rank)
         if world == 1 and not args.no_cpu_baseline:

@@ -78,7 +78,10 @@ struct fdtd_ctx {
 
     int nx = 0, ny = 0, nz = 0; // global extents
     int s0 = 0, sn = 0, gn = 0; // slab axis: first global row held, rows held, global rows
-    int pitch = 0;
+    int pitch = 0;     // floats from one row of a field array to the next
+    int cpitch = 0;    // bytes from one row of the code array to the next (2-D)
+    size_t celems = 0, clead = 0; // the code array's counterparts of elems and lead
+    std::vector<std::pair<float *, size_t>> state_bufs; // what a checkpoint holds: (start, floats)
     size_t rows_store = 0; // storage rows per array (halo rows included)
     size_t elems = 0;      // floats per array without the slack
     int chunk_rows = 1;
@@ -180,6 +183,7 @@ int alloc_field(fdtd_ctx *c, float **out)
     int rc = dev_alloc(c, &base, c->elems + 2 * kSlack);
     if (rc) return rc;
     *out = base + kSlack + c->lead;
+    c->state_bufs.push_back({base + kSlack, c->elems});
     return 0;
 }
 
@@ -192,6 +196,7 @@ Grid2D grid2d(const fdtd_ctx *c)
     g.gy0 = c->s0;
     g.gny = c->gn;
     g.pitch = c->pitch;
+    g.cpitch = c->cpitch;
     g.dt = p.dt;
     g.kh_x = p.dt / (p.mu0 * p.dx);
     g.kh_y = p.dt / (p.mu0 * p.dy);
@@ -303,7 +308,7 @@ int upload_codes(fdtd_ctx *c)
 {
     // owned rows only; halo rows keep the default code (their E is never updated here)
     const size_t rows = c->is2d() ? (size_t)c->sn : (size_t)c->sn * c->ny;
-    uint8_t *dst = c->code + (c->is2d() ? (size_t)c->pitch : (size_t)c->ny * c->pitch);
+    uint8_t *dst = c->code + (c->is2d() ? (size_t)c->cpitch : (size_t)c->ny * c->pitch);
     std::vector<uint8_t> dev(c->codes_host.size());
     int top = 0;
     for (size_t i = 0; i < dev.size(); ++i) {
@@ -311,7 +316,8 @@ int upload_codes(fdtd_ctx *c)
         top = std::max(top, (int)dev[i]);
     }
     c->ntab = top + 1;
-    HIPCHK(hipMemcpy2DAsync(dst, c->pitch, dev.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpy2DAsync(dst, c->is2d() ? c->cpitch : c->pitch, dev.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice,
+                            c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -365,6 +371,7 @@ int deep_halo_kernel(fdtd_ctx *c, int sides, bool unpack, float *b0, float *b1, 
     a.buf[1] = b1;
     a.nx = c->nx;
     a.pitch = c->pitch;
+    a.cpitch = c->cpitch;
     a.nyl = c->sn;
     a.depth = c->tb_steps;
     a.sides = sides;
@@ -974,30 +981,55 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     // plane is one flat run of 16-byte words, so rows only need 64-byte alignment and a narrow
     // grid (nx = 265) wastes 3 % of the lanes instead of 17 %.
     const int quantum = (!c->is2d() && c->kernel == FDTD_KERNEL_FUSED) ? 16 : 64;
-    c->pitch = (c->nx + quantum - 1) / quantum * quantum + skew * 64;
+    const int row_pitch = (c->nx + quantum - 1) / quantum * quantum + skew * 64;
+    // Multi-step sweep: the six arrays a pass reads (H and both levels of ez and dz) are interleaved
+    // row by row in one allocation, and so are the six it writes: a band of waves marching up the
+    // grid then walks ONE run of memory per direction, six rows at a time, instead of six runs far
+    // apart, which is what DRAM pages want (16384^2: FDTD_TB_INTERLEAVE=0 gives the separate arrays).
+    bool interleave = c->kernel == FDTD_KERNEL_MULTISTEP;
+    if (const char *v = std::getenv("FDTD_TB_INTERLEAVE")) interleave = interleave && std::atoi(v) != 0;
+    c->pitch = interleave ? 6 * row_pitch : row_pitch;
+    c->cpitch = row_pitch;
     c->rows_store = c->is2d() ? (size_t)c->sn + 2 * c->halo : ((size_t)c->sn + 2) * c->ny;
     c->elems = c->rows_store * c->pitch;
     c->lead = (size_t)(c->halo - 1) * c->pitch;
+    c->celems = c->rows_store * (c->is2d() ? (size_t)c->cpitch : (size_t)c->pitch);
+    c->clead = (size_t)(c->halo - 1) * c->cpitch;
 
     int rc = 0;
-    const bool two_h = c->one_pass();
-    const int levels = c->kernel == FDTD_KERNEL_MULTISTEP ? 4 : 2;
-    for (int k = 0; k < 3 && !rc; ++k) {
-        const bool used_h = c->is2d() ? k < 2 : true;  // hx, hy
-        const bool used_ed = c->is2d() ? k == 2 : true; // dz, ez
-        if (used_h) {
-            rc = alloc_field(c, &c->h[k][0]);
-            if (!rc && two_h) rc = alloc_field(c, &c->h[k][1]);
+    if (interleave) {
+        for (int grp = 0; grp < 2 && !rc; ++grp) {
+            float *base = nullptr;
+            if ((rc = dev_alloc(c, &base, c->elems + 2 * kSlack))) break;
+            float *first = base + kSlack + c->lead;
+            c->state_bufs.push_back({base + kSlack, c->elems});
+            c->h[0][grp] = first;
+            c->h[1][grp] = first + row_pitch;
+            c->e[2][2 * grp] = first + 2 * (size_t)row_pitch;
+            c->e[2][2 * grp + 1] = first + 3 * (size_t)row_pitch;
+            c->d[2][2 * grp] = first + 4 * (size_t)row_pitch;
+            c->d[2][2 * grp + 1] = first + 5 * (size_t)row_pitch;
         }
-        for (int l = 0; l < levels && used_ed && !rc; ++l) {
-            rc = alloc_field(c, &c->e[k][l]);
-            if (!rc) rc = alloc_field(c, &c->d[k][l]);
+    } else {
+        const bool two_h = c->one_pass();
+        const int levels = c->kernel == FDTD_KERNEL_MULTISTEP ? 4 : 2;
+        for (int k = 0; k < 3 && !rc; ++k) {
+            const bool used_h = c->is2d() ? k < 2 : true;  // hx, hy
+            const bool used_ed = c->is2d() ? k == 2 : true; // dz, ez
+            if (used_h) {
+                rc = alloc_field(c, &c->h[k][0]);
+                if (!rc && two_h) rc = alloc_field(c, &c->h[k][1]);
+            }
+            for (int l = 0; l < levels && used_ed && !rc; ++l) {
+                rc = alloc_field(c, &c->e[k][l]);
+                if (!rc) rc = alloc_field(c, &c->d[k][l]);
+            }
         }
     }
     if (rc) return rc;
     uint8_t *code_base = nullptr;
-    if ((rc = dev_alloc(c, &code_base, c->elems + 2 * kSlack))) return rc;
-    c->code = code_base + kSlack + c->lead;
+    if ((rc = dev_alloc(c, &code_base, c->celems + 2 * kSlack))) return rc;
+    c->code = code_base + kSlack + c->clead;
     if ((rc = dev_alloc(c, &c->table, (size_t)FDTD_MAX_CODES))) return rc;
     if ((rc = dev_alloc(c, &c->table_wide, (size_t)FDTD_MAX_CODES))) return rc;
 
@@ -1566,17 +1598,11 @@ struct CheckpointHeader {
     int64_t step, elems;
 };
 
+// Every allocation that holds time-dependent state, in the order it was made (c->elems floats each).
 std::vector<float *> state_arrays(fdtd_ctx *c)
 {
     std::vector<float *> v;
-    for (int k = 0; k < 3; ++k)
-        for (int g = 0; g < 2; ++g)
-            if (c->h[k][g]) v.push_back(c->h[k][g] - c->lead);
-    for (int k = 0; k < 3; ++k)
-        for (int l = 0; l < 4; ++l) {
-            if (c->d[k][l]) v.push_back(c->d[k][l] - c->lead);
-            if (c->e[k][l]) v.push_back(c->e[k][l] - c->lead);
-        }
+    for (const auto &b : c->state_bufs) v.push_back(b.first);
     return v;
 }
 

@@ -56,6 +56,7 @@ struct ProbeList {
 // halo rows (zero outside the grid).  Every pointer addresses storage row 0.
 struct Grid2D {
     int nx, nyl, gy0, gny, pitch;
+    int cpitch; // row pitch of the material code array in bytes (the field arrays may be interleaved row by row)
     float dt;
     float kh_x, kh_y; // dt/(mu0*dx), dt/(mu0*dy)   (fdtd_calculations.cu:49,63)
     float cx, cy;     // dt/dx, dt/dy               (fdtd_calculations.cu:92-93)
@@ -192,7 +193,7 @@ struct HaloDeep {
     float *arr[6];   // hx, hy, ez newest, ez previous, dz newest, dz previous (local row -1 at storage row 0)
     uint8_t *code;
     float *buf[2];   // side 0 = lower neighbour, side 1 = upper neighbour
-    int nx, pitch, nyl, depth;
+    int nx, pitch, cpitch, nyl, depth;
     int sides;       // bit mask of the sides to handle
     int unpack;      // 0: owned rows -> buf; 1: buf -> halo rows
 };

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void fdtd2d_de(const Sweep2D a)
         a.dz_w[o] = dn;
     }
     if (x >= 1) {
-        const MatEntry m = a.table[a.code[o]];
+        const MatEntry m = a.table[a.code[(size_t)(j + 1) * g.cpitch + x]];
         a.ez_w[o] = e_update(m, g.dt, a.ez_n[o], a.ez_w[o], dn, d0, d1);
     }
 }
@@ -306,10 +306,11 @@ __global__ __launch_bounds__(256) void fdtd2d_halo_deep(const HaloDeep a)
             *slot = a.arr[arr][cell];
     } else {
         uint8_t *slot = (uint8_t *)(a.buf[side] + (size_t)6 * a.depth * a.nx) + (size_t)r * a.nx + x;
+        const size_t ccell = (size_t)(row + 1) * a.cpitch + x;
         if (a.unpack)
-            a.code[cell] = *slot;
+            a.code[ccell] = *slot;
         else
-            *slot = a.code[cell];
+            *slot = a.code[ccell];
     }
 }
 

@@ -47,7 +47,7 @@ struct Row2D {
 // 0 = the first (the streaming loads of ez^n and hx), 1 = the last (the loads of
 // the row below, after which no block reads those lines again).
 template <int POL>
-__device__ __forceinline__ void load_row(Row2D &r, const Sweep2D &a, size_t off, size_t pitch, bool act,
+__device__ __forceinline__ void load_row(Row2D &r, const Sweep2D &a, size_t off, size_t coff, size_t pitch, bool act,
                                          bool edge_r, bool edge_l)
 {
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -62,7 +62,7 @@ __device__ __forceinline__ void load_row(Row2D &r, const Sweep2D &a, size_t off,
     r.e1 = act ? ld4_stream(a.ez_w + off) : zero;
     r.d0 = act ? ld4_stream(a.dz_n + off) : zero;
     r.d1 = act ? ld4_stream(a.dz_w + off) : zero;
-    r.cd = act ? *(const unsigned *)(a.code + off) : 0u;
+    r.cd = act ? *(const unsigned *)(a.code + coff) : 0u;
     r.e_edge = edge_r ? a.ez_n[off + 4] : 0.f;
     r.hy_lo = edge_l ? a.hy_r[off - 1] : 0.f;
     r.ez_lo = edge_l ? a.ez_n[off - 1] : 0.f;
@@ -128,10 +128,11 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const Block
 
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     size_t off = (size_t)(j0 + 1) * pitch + x4;
+    size_t coff = (size_t)(j0 + 1) * g.cpitch + x4;
 
     // Loads of the first row and of the row below it, all issued before any use.
     Row2D cur;
-    load_row<POL>(cur, a, off, pitch, act, edge_r, edge_l);
+    load_row<POL>(cur, a, off, coff, pitch, act, edge_r, edge_l);
     f4 ezc = act ? *(const f4 *)(a.ez_n + off) : zero;
     f4 hxp = zero, ezm = zero;
     if (act) {
@@ -217,9 +218,9 @@ __global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const Block
         ezc = r.ezn;
     };
 
-    for (int j = j0; j < j1 - 1; ++j, off += pitch) {
+    for (int j = j0; j < j1 - 1; ++j, off += pitch, coff += g.cpitch) {
         Row2D nxt;
-        load_row<POL>(nxt, a, off + pitch, pitch, act, edge_r, edge_l);
+        load_row<POL>(nxt, a, off + pitch, coff + g.cpitch, pitch, act, edge_r, edge_l);
         row(cur, j, off);
         cur = nxt;
     }

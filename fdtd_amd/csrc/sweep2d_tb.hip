@@ -271,7 +271,8 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), 2) void fdtd2d_sweep_tb(
         r.dz = ld ? ld4(a.dz_n + off) : zero;
         r.dzp = ld ? ld4(a.dz_p + off) : zero;
         r.ezu = ld ? ld4(a.ez_n + off + pitch) : zero;
-        r.cd = (!ONE && ld) ? *(const unsigned *)(a.code + off) : 0u; // a single material: no code is looked at
+        // (a single material: no code is looked at)
+        r.cd = (!ONE && ld) ? *(const unsigned *)(a.code + (long)(j + 1) * g.cpitch + x4) : 0u;
     };
 
     auto march = [&](auto inner) {

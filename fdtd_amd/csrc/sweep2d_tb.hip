@@ -167,14 +167,19 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), 2) void fdtd2d_sweep_tb(
         StageOut o;
         // the four table rows of this lane's cells first: the E update at the end of the stage needs
         // them, and the H and D arithmetic in between covers the LDS latency
+        // (wide rows: when the four cells of every lane of the wave hold one code each -- always so
+        // on a map upsampled by a multiple of four -- one row per lane serves all four cells; a
+        // wave with a mixed word anywhere reads a row per cell just before it is used)
         MatEntry m[4];
-        MatCoef mw[4];
+        MatCoef mu;
+        bool words_uniform = false;
+        if (!ONE && WIDE) {
+            const unsigned c0 = in.cd & 0xffu;
+            words_uniform = __all(in.cd == c0 * 0x01010101u);
+            mu = tabw[c0];
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (!ONE && WIDE)
-                mw[i] = tabw[(in.cd >> (8 * i)) & 0xffu];
-            else
-                m[i] = ONE ? a.one : tab[(in.cd >> (8 * i)) & 0xffu];
+            for (int i = 0; i < 4; ++i) m[i] = ONE ? a.one : tab[(in.cd >> (8 * i)) & 0xffu];
         }
         const float e_right = __shfl_down(in.ez.x, 1);
         const float er[4] = {in.ez.y, in.ez.z, in.ez.w, e_right};
@@ -201,11 +206,26 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), 2) void fdtd2d_sweep_tb(
             o.dz[i] = dn;
         }
 
+        if (!ONE && WIDE) {
+            if (words_uniform) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            o.ez[i] = !(IN || (gy_ez && m_ez[i])) ? ezp[i]
-                      : (!ONE && WIDE)             ? e_update_wide(mw[i], in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
-                                                   : e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
+                for (int i = 0; i < 4; ++i)
+                    o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update_wide(mu, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                                                         : ezp[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const MatCoef mi = tabw[(in.cd >> (8 * i)) & 0xffu];
+                    o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update_wide(mi, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                                                         : ezp[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                                                     : ezp[i];
+        }
         return o;
     };
 

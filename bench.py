@@ -132,6 +132,9 @@ def main():
     ap.add_argument("--allow-host-halo", action="store_true",
                     help="N > 1: if RCCL cannot initialise, run with halos staged through the host (flagged in the output) "
                          "instead of failing")
+    ap.add_argument("--no-profile", action="store_true",
+                    help="no HIP-event pairs around the sweeps (two more host calls per launch: they dominate the step "
+                         "time of grids that are launch-bound); the roofline block is then left out")
     ap.add_argument("--no-one-step-leg", action="store_true", help="skip the extra one-step-sweep measurement")
     ap.add_argument("--tissue", type=int, default=0, metavar="U",
                     help="config 3: the 265x490 body slice data/pgmdata/v1_00800.pgm upsampled U times (32: 8480x15680), "
@@ -256,7 +259,13 @@ def main():
         torch.cuda.synchronize()
 
     stepper.step(args.warmup)
-    solver.profile_begin(args.steps)
+    if args.snapshot_every > 0:
+        # both staging sets (device copy + pinned host buffer) are allocated by the first two snapshots
+        for _ in range(2):
+            solver.snapshot_async(B.EZ)
+        solver.snapshot_wait()
+    if not args.no_profile:
+        solver.profile_begin(args.steps)
     barrier()
     t0 = time.perf_counter()
     snapshots = 0
@@ -269,13 +278,16 @@ def main():
             if done % args.snapshot_every == 0:
                 solver.snapshot_async(B.EZ)            # waits for the previous one, then queues the next
                 snapshots += 1
+        t_tail = time.perf_counter()
         solver.snapshot_wait()
+        tail_ms = (time.perf_counter() - t_tail) * 1e3
     else:
+        tail_ms = 0.0
         stepper.step(args.steps)
     solver.sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    sweep_ms, sweep_steps = solver.profile_read_launches(args.steps)
+    sweep_ms, sweep_steps = solver.profile_read_launches(args.steps) if not args.no_profile else ([], [])
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -335,7 +347,8 @@ def main():
                 "parallelism": f"slab{world}" if world > 1 else "single",
                 "halo": halo,
                 "output": (f"{snapshots} ez snapshots per rank (async D2H on a side stream) + {nprobes} probes x "
-                           f"{solver.lib.fdtd_probe_fields(solver._ctx)} fields every step") if snapshots
+                           f"{solver.lib.fdtd_probe_fields(solver._ctx)} fields every step; the timed region ends with "
+                           f"{tail_ms:.1f} ms of waiting for the last snapshot's D2H") if snapshots
                 else f"{nprobes} probe(s) every step",
             },
             "roofline": {
@@ -354,7 +367,10 @@ def main():
                 "launches": launches,
             },
         }
-        if traffic:
+        if args.no_profile:
+            del out["roofline"]
+            multistep = False
+        if traffic and not args.no_profile:
             out["roofline"]["traffic_GBs"] = traffic / (sweep_avg_ms * 1e-3) / 1e9
             out["roofline"]["traffic_frac_of_peak"] = traffic / (sweep_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         if multistep:
@@ -367,7 +383,8 @@ def main():
             issue = issue_bound(solver, full_k, sweep_avg_ms)
             if issue:
                 out["roofline"]["issue_bound"] = issue
-        if world == 1 and not is3d and not args.no_one_step_leg and not args.tissue and kernel_name != "fdtd2d_sweep":
+        if world == 1 and not is3d and not args.no_one_step_leg and not args.no_profile and not args.tissue \
+                and kernel_name != "fdtd2d_sweep":
             solver.close()
             out["roofline_one_step"] = one_step_leg(params, local_rank, cells_per_rank)
         if world == 1 and not args.no_cpu_baseline:

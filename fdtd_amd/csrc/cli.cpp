@@ -23,8 +23,11 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fdtd_amd.h"
@@ -85,6 +88,87 @@ static void write_field(const fdtd_params &p, const char *family, char axis, int
         std::fclose(f);
     }
 }
+
+// The per-plane files of one output iteration are formatted and written by a second thread while
+// the main thread steps the fields on to the next output iteration (the reference hands each step's
+// fields to copy threads and a writer thread, fdtd.cu:132-155, 253).  Two sets of host buffers:
+// the main thread only waits when both are still being written.
+class PlaneWriter {
+public:
+    struct Job {
+        int iteration = 0;
+        std::vector<float> field[9]; // empty: the 2-D mode does not hold that field (written as zeros)
+        bool busy = false;
+    };
+
+    PlaneWriter(const fdtd_params &p) : p_(p), thread_([this] { run(); }) {}
+    ~PlaneWriter()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        thread_.join();
+    }
+    // A set of buffers nobody is writing from.
+    Job *acquire()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return !jobs_[0].busy || !jobs_[1].busy; });
+        Job *j = !jobs_[0].busy ? &jobs_[0] : &jobs_[1];
+        j->busy = true;
+        return j;
+    }
+    void submit(Job *j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            queue_.push_back(j);
+        }
+        cv_.notify_all();
+    }
+    void drain()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return queue_.empty() && !jobs_[0].busy && !jobs_[1].busy; });
+    }
+
+private:
+    void run()
+    {
+        static const char *family[3] = {"H", "D", "E"};
+        const size_t cells = (size_t)p_.nx * p_.ny * p_.nz;
+        std::vector<float> zeros;
+        for (;;) {
+            Job *j;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+                if (queue_.empty()) return;
+                j = queue_.front();
+                queue_.erase(queue_.begin());
+            }
+            for (int f = 0; f < 9; f++) {
+                if (j->field[f].empty() && zeros.empty()) zeros.assign(cells, 0.0f);
+                write_field(p_, family[f / 3], "xyz"[f % 3], j->iteration, j->field[f].empty() ? zeros : j->field[f]);
+            }
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                j->busy = false;
+            }
+            cv_.notify_all();
+        }
+    }
+
+    fdtd_params p_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    Job jobs_[2];
+    std::vector<Job *> queue_;
+    bool stop_ = false;
+    std::thread thread_;
+};
 
 // writeResults (fdtd.cu:1197-1285): for every source the x, y and z grid lines through it, one text
 // line per cell: 1-based indices, then D, H, E (x y z each).  Read as windows, not whole fields.
@@ -185,8 +269,7 @@ int main(int argc, char **argv)
 
     const bool is2d = opt.mode == FDTD_MODE_2D_TMZ || (opt.mode == FDTD_MODE_AUTO && p.nz == 1);
     const size_t cells = (size_t)p.nx * p.ny * p.nz;
-    std::vector<float> host(cells);
-    static const char *family[3] = {"H", "D", "E"};
+    PlaneWriter writer(p);
     const auto t0 = std::chrono::steady_clock::now();
     for (int first = 0; first < p.iterations;) {
         // all the steps up to the next iteration that writes results go into one call, so that
@@ -199,20 +282,24 @@ int main(int argc, char **argv)
         if (output_every > 0 && i % output_every == 0) {
             std::printf("Writing results for iteration %d\n", i + 1);
             if (axis_lines) write_axis_lines(ctx, p, is2d, i);
-            for (int fam = 0; planes && fam < 3; fam++)
-                for (int k = 0; k < 3; k++) {
-                    const int field = fam * 3 + k;
+            if (planes) {
+                PlaneWriter::Job *job = writer.acquire();
+                job->iteration = i;
+                for (int field = 0; field < 9; field++) {
                     const bool held = !is2d || field == FDTD_HX || field == FDTD_HY || field == FDTD_DZ || field == FDTD_EZ;
-                    if (held) {
-                        if (fdtd_read_field(ctx, field, 0, host.data(), cells)) die("reading a field");
-                    } else {
-                        std::fill(host.begin(), host.end(), 0.0f);
+                    if (!held) {
+                        job->field[field].clear();
+                        continue;
                     }
-                    write_field(p, family[fam], "xyz"[k], i, host);
+                    job->field[field].resize(cells);
+                    if (fdtd_read_field(ctx, field, 0, job->field[field].data(), cells)) die("reading a field");
                 }
+                writer.submit(job); // formatted and written while the next iterations run
+            }
         }
     }
     if (fdtd_sync(ctx)) die("synchronizing");
+    writer.drain();
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("\n%d iterations, %.3f s, %.1f Mcell-updates/s (I/O included)\n", p.iterations, sec,
                 (double)cells * p.iterations / sec / 1e6);

@@ -115,7 +115,11 @@ struct fdtd_ctx {
     int halo_top[2] = {0, 0};
     bool spp_fixed = false; // steps per pass do not depend on the materials (slabs, or set by the caller)
     int ntab_eff() const { return std::max(ntab, ntab_halo); }
-    std::vector<uint8_t> codes_host; // slab cells, x fastest; empty = all default
+    std::vector<uint8_t> codes_host; // slab cells, x fastest; empty = all default (or kept as codes_base)
+    // materials loaded with upsample > 1: the slice images as read (one per owned plane, all rows),
+    // expanded on the device; codes_up = 0 when not in use
+    std::vector<uint8_t> codes_base;
+    int codes_up = 0, base_x = 0, base_y = 0;
     std::vector<float> rp_host[6];
     SourceList src; // global coordinates
 
@@ -967,6 +971,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        if (std::getenv("FDTD_XSTREAM_NORMAL")) greatest = 0;
         HIPCHK(hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, greatest));
     }
     HIPCHK(hipEventCreateWithFlags(&c->snap_ev, hipEventDisableTiming));
@@ -1112,6 +1117,8 @@ int fdtd_set_codes(fdtd_ctx *c, const uint8_t *codes, size_t count)
     }
     if (use_device(c)) return -10;
     c->codes_host.assign(codes, codes + count);
+    c->codes_up = 0;
+    c->codes_base.clear();
     c->halo_stale = true;
     return upload_codes(c);
 }
@@ -1129,20 +1136,75 @@ int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir
     for (int i = 0; i < FDTD_MAX_CODES; ++i) c->mats[i] = table[i];
     c->mats[kDefaultCode] = def;
 
-    c->codes_host.assign(c->slab_cells(), 0);
-    if (c->is2d()) {
-        char path[2048];
-        std::snprintf(path, sizeof path, "%s/v1_%05d.pgm", pgm_dir, first_slice);
-        rc = read_pgm_slice(path, c->nx, c->ny, upsample, c->s0, c->sn, c->codes_host.data());
-        if (rc) return rc;
-    } else {
-        for (int k = 0; k < c->sn; ++k) {
-            char path[2048];
-            std::snprintf(path, sizeof path, "%s/v1_%05d.pgm", pgm_dir, c->s0 + k + first_slice);
-            rc = read_pgm_slice(path, c->nx, c->ny, upsample, 0, c->ny,
-                                c->codes_host.data() + (size_t)k * c->nx * c->ny);
-            if (rc) return rc;
+    c->codes_host.clear();
+    c->codes_base.clear();
+    c->codes_up = 0;
+    const int planes = c->is2d() ? 1 : c->sn;
+    if (upsample > 1) {
+        // The slice images go to the device as they are and a kernel repeats every pixel
+        // upsample x upsample times into the code array: a 65536^2 map never exists on the host.
+        if (upsample < 1 || c->nx % upsample || c->ny % upsample) {
+            set_error("upsample must divide nx and ny");
+            return -3;
         }
+        const int bx = c->nx / upsample, by = c->ny / upsample;
+        c->codes_base.resize((size_t)planes * bx * by);
+        for (int k = 0; k < planes; ++k) {
+            char path[2048];
+            std::snprintf(path, sizeof path, "%s/v1_%05d.pgm", pgm_dir, (c->is2d() ? 0 : c->s0 + k) + first_slice);
+            if ((rc = read_pgm_base(path, bx, by, c->codes_base.data() + (size_t)k * bx * by))) return rc;
+        }
+        c->codes_up = upsample;
+        c->base_x = bx;
+        c->base_y = by;
+        // device codes; the highest one among the pixels this slab's rows come from
+        std::vector<uint8_t> dev(c->codes_base.size());
+        const int r0 = c->is2d() ? c->s0 / upsample : 0, r1 = c->is2d() ? (c->s0 + c->sn - 1) / upsample : by - 1;
+        int top = 0;
+        for (int k = 0; k < planes; ++k)
+            for (int r = 0; r < by; ++r)
+                for (int x = 0; x < bx; ++x) {
+                    const size_t i = ((size_t)k * by + r) * bx + x;
+                    dev[i] = device_code(c->codes_base[i]);
+                    if (r >= r0 && r <= r1) top = std::max(top, (int)dev[i]);
+                }
+        c->ntab = top + 1;
+        uint8_t *dbase = nullptr;
+        HIPCHK(hipMalloc((void **)&dbase, dev.size()));
+        hipError_t e = hipMemcpyAsync(dbase, dev.data(), dev.size(), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            ExpandCodes x;
+            x.code = c->code + (c->is2d() ? (size_t)c->cpitch : (size_t)c->ny * c->pitch);
+            x.base = dbase;
+            x.nx = c->nx;
+            x.bx = bx;
+            x.by = by;
+            x.up = upsample;
+            x.rows = c->is2d() ? c->sn : c->ny;
+            x.row0 = c->is2d() ? c->s0 : 0;
+            x.planes = planes;
+            x.row_pitch = c->is2d() ? c->cpitch : c->pitch;
+            x.plane_pitch = c->is2d() ? 0 : (long long)c->ny * c->pitch;
+            launch_expand_codes(x, c->stream);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(dbase);
+        if (e != hipSuccess) {
+            set_error(std::string("fdtd_load_materials: ") + hipGetErrorString(e));
+            return -10;
+        }
+        if ((rc = upload_table(c))) return rc;
+        c->halo_stale = true;
+        return 0;
+    }
+    c->codes_host.assign(c->slab_cells(), 0);
+    for (int k = 0; k < planes; ++k) {
+        char path[2048];
+        std::snprintf(path, sizeof path, "%s/v1_%05d.pgm", pgm_dir, (c->is2d() ? 0 : c->s0 + k) + first_slice);
+        rc = c->is2d() ? read_pgm_slice(path, c->nx, c->ny, 1, c->s0, c->sn, c->codes_host.data())
+                       : read_pgm_slice(path, c->nx, c->ny, 1, 0, c->ny, c->codes_host.data() + (size_t)k * c->nx * c->ny);
+        if (rc) return rc;
     }
     if ((rc = upload_table(c))) return rc;
     c->halo_stale = true;
@@ -1172,37 +1234,48 @@ int fdtd_get_rp(fdtd_ctx *c, int face, float *data, size_t count)
 
 int fdtd_setup_mur_from_materials(fdtd_ctx *c)
 {
-    if (c->sn != c->gn) {
-        set_error("fdtd_setup_mur_from_materials needs the whole grid in one slab");
+    if (c->deep() && c->sn != c->gn) {
+        // a multi-step slab also applies the Mur update to the neighbours' rows it recomputes in its
+        // halos, and it does not hold their materials on the host
+        set_error("fdtd_setup_mur_from_materials: not available on a slab of the multi-step mode (set the planes "
+                  "with fdtd_set_rp, or use FDTD_KERNEL_FUSED)");
         return -3;
     }
     if (use_device(c)) return -10;
     const int nx = c->nx, ny = c->ny, nz = c->nz;
+    // A slab fills in the entries of the cells it holds -- the only ones its Mur launches look at;
+    // the rest of its planes keeps the values derived from the defaults.
+    auto held = [&](int y, int z) { const int s = c->is2d() ? y : z; return s >= c->s0 && s < c->s0 + c->sn; };
     auto mat = [&](int x, int y, int z) -> const MaterialRow & {
+        const int ly = c->is2d() ? y - c->s0 : y, lz = c->is2d() ? 0 : z - c->s0;
+        if (c->codes_up > 0)
+            return c->mats[c->codes_base[((size_t)lz * c->base_y + y / c->codes_up) * c->base_x + x / c->codes_up]];
         if (c->codes_host.empty()) return c->mats[kDefaultCode];
-        return c->mats[c->codes_host[((size_t)z * ny + y) * nx + x]];
+        return c->mats[c->codes_host[((size_t)lz * (c->is2d() ? c->sn : ny) + ly) * nx + x]];
     };
     for (int z = 0; z < nz; ++z)
-        for (int y = 0; y < ny; ++y)
+        for (int y = 0; y < ny; ++y) {
+            if (!held(y, z)) continue;
             for (int k = 0; k < 2; ++k) {
                 const size_t r = ((size_t)z * ny + y) * 2 + k;
                 c->rp_host[FDTD_RP_X0][r] = rp_value(c->p, mat(k, y, z), true);
                 c->rp_host[FDTD_RP_XEND][r] = rp_value(c->p, mat(nx - 2 + k, y, z), true);
             }
+        }
     for (int z = 0; z < nz; ++z)
         for (int k = 0; k < 2; ++k)
             for (int x = 0; x < nx; ++x) {
                 const size_t r = ((size_t)z * 2 + k) * nx + x;
-                c->rp_host[FDTD_RP_Y0][r] = rp_value(c->p, mat(x, k, z), false);
-                c->rp_host[FDTD_RP_YEND][r] = rp_value(c->p, mat(x, ny - 2 + k, z), false);
+                if (held(k, z)) c->rp_host[FDTD_RP_Y0][r] = rp_value(c->p, mat(x, k, z), false);
+                if (held(ny - 2 + k, z)) c->rp_host[FDTD_RP_YEND][r] = rp_value(c->p, mat(x, ny - 2 + k, z), false);
             }
     if (!c->is2d())
         for (int k = 0; k < 2; ++k)
             for (int y = 0; y < ny; ++y)
                 for (int x = 0; x < nx; ++x) {
                     const size_t r = ((size_t)k * ny + y) * nx + x;
-                    c->rp_host[FDTD_RP_Z0][r] = rp_value(c->p, mat(x, y, k), false);
-                    c->rp_host[FDTD_RP_ZEND][r] = rp_value(c->p, mat(x, y, nz - 2 + k), false);
+                    if (held(y, k)) c->rp_host[FDTD_RP_Z0][r] = rp_value(c->p, mat(x, y, k), false);
+                    if (held(y, nz - 2 + k)) c->rp_host[FDTD_RP_ZEND][r] = rp_value(c->p, mat(x, y, nz - 2 + k), false);
                 }
     for (int f = 0; f < 6; ++f) {
         int rc = upload_rp(c, f);

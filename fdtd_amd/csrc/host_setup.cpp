@@ -317,16 +317,12 @@ int read_material_specs(const char *path, MaterialRow table[FDTD_MAX_CODES], boo
 // following integers in sequence, x fastest -- the declared width/height are
 // not used to address the pixels.  With upsample u > 1 the sequence fills an
 // (nx/u) x (ny/u) image whose pixels are repeated u x u times.
-int read_pgm_slice(const char *path, int nx, int ny, int upsample, int y0, int rows, uint8_t *dst)
+int read_pgm_base(const char *path, int bx, int by, uint8_t *base)
 {
     std::string text;
     if (!read_file(path, text)) {
         set_error(std::string("Couldn't open file ") + path);
         return -1;
-    }
-    if (upsample < 1 || nx % upsample || ny % upsample) {
-        set_error("upsample must divide nx and ny");
-        return -3;
     }
     Scanner in(text);
     int w, h;
@@ -334,9 +330,8 @@ int read_pgm_slice(const char *path, int nx, int ny, int upsample, int y0, int r
         set_error(std::string(path) + ": bad PGM header");
         return -2;
     }
-    const int bx = nx / upsample, by = ny / upsample;
-    std::vector<uint8_t> base((size_t)bx * by);
-    for (size_t i = 0; i < base.size(); ++i) {
+    const size_t n = (size_t)bx * by;
+    for (size_t i = 0; i < n; ++i) {
         int code;
         if (!in.integer(&code)) {
             set_error(std::string(path) + ": fewer than nx*ny pixel values");
@@ -348,6 +343,18 @@ int read_pgm_slice(const char *path, int nx, int ny, int upsample, int y0, int r
         }
         base[i] = (uint8_t)code;
     }
+    return 0;
+}
+
+int read_pgm_slice(const char *path, int nx, int ny, int upsample, int y0, int rows, uint8_t *dst)
+{
+    if (upsample < 1 || nx % upsample || ny % upsample) {
+        set_error("upsample must divide nx and ny");
+        return -3;
+    }
+    const int bx = nx / upsample, by = ny / upsample;
+    std::vector<uint8_t> base((size_t)bx * by);
+    if (int rc = read_pgm_base(path, bx, by, base.data())) return rc;
     for (int r = 0; r < rows; ++r) {
         const uint8_t *src = &base[(size_t)((y0 + r) / upsample) * bx];
         uint8_t *row = dst + (size_t)r * nx;

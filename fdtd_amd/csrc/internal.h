@@ -198,6 +198,17 @@ struct HaloDeep {
     int unpack;      // 0: owned rows -> buf; 1: buf -> halo rows
 };
 
+// Nearest-neighbour upsampling of base images of device codes into the code array: plane k, row j,
+// column x takes base[k][(row0 + j) / up][x / up].
+struct ExpandCodes {
+    uint8_t *code;         // first owned row (2-D) / plane (3-D)
+    const uint8_t *base;   // planes x by x bx bytes
+    int nx, bx, by, up;
+    int rows, row0;        // rows per plane written, global index of the first (2-D slabs: the slab's first row)
+    int planes;
+    long long row_pitch, plane_pitch; // bytes
+};
+
 struct Probe2D {
     Grid2D g;
     const float *hx, *hy, *dz, *ez;
@@ -229,6 +240,7 @@ void launch_h3d(const Sweep3D &a, void *stream);
 void launch_de3d(const Sweep3D &a, void *stream);
 void launch_mur3d(const Mur3D &a, void *stream);
 void launch_halo_deep(const HaloDeep &a, void *stream);
+void launch_expand_codes(const ExpandCodes &a, void *stream);
 void launch_probe2d(const Probe2D &a, void *stream);
 void launch_probe3d(const Probe3D &a, void *stream);
 const char *sweep2d_kernel_name();
@@ -244,6 +256,9 @@ int setup_sources(fdtd_params *p);
 MatCoef make_coef(const MaterialRow &m, float dt, float eps0, int ecoef);
 float rp_value(const fdtd_params &p, const MaterialRow &m, bool x_face);
 int read_material_specs(const char *path, MaterialRow table[FDTD_MAX_CODES], bool present[FDTD_MAX_CODES]);
+// The pixel values of one slice file read in sequence into a bx x by image (loadMaterials' token
+// semantics, fdtd.cu:920-931).
+int read_pgm_base(const char *path, int bx, int by, uint8_t *base);
 // Codes of one z slice for rows [y0, y0 + rows) of an nx-wide grid.
 int read_pgm_slice(const char *path, int nx, int ny, int upsample, int y0, int rows, uint8_t *dst);
 

@@ -10,6 +10,8 @@
 // host build of the same equations.  The kernels are bandwidth bound (about
 // 0.5 flop per byte): no MFMA, wide coalesced loads, neighbours through lane
 // shuffles.  The fused 2-D sweep lives in sweep2d.hip.
+#include <algorithm>
+
 #include "device_math.h"
 
 namespace fdtd {
@@ -314,6 +316,23 @@ __global__ __launch_bounds__(256) void fdtd2d_halo_deep(const HaloDeep a)
     }
 }
 
+// One thread per four cells of a row (one 4-byte store); block id = (plane * rows + row) * xblocks + x block.
+__global__ __launch_bounds__(256) void fdtd_expand_codes(const ExpandCodes a, const unsigned xblocks)
+{
+    const unsigned xb = blockIdx.x % xblocks;
+    const long line = blockIdx.x / xblocks;
+    const int x4 = (int)(xb * 256 + threadIdx.x) * 4;
+    if (x4 >= a.nx) return;
+    const int j = (int)(line % a.rows);
+    const long k = line / a.rows;
+    const uint8_t *src = a.base + ((size_t)k * a.by + (size_t)((a.row0 + j) / a.up)) * a.bx;
+    unsigned word = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (x4 + i < a.nx) word |= (unsigned)src[(x4 + i) / a.up] << (8 * i);
+    *(unsigned *)(a.code + (size_t)k * a.plane_pitch + (size_t)j * a.row_pitch + x4) = word;
+}
+
 __global__ void fdtd3d_probe(const Probe3D a)
 {
     const int i = threadIdx.x;
@@ -374,6 +393,22 @@ void launch_mur3d(const Mur3D &a, void *stream)
 void launch_halo_deep(const HaloDeep &a, void *stream)
 {
     hipLaunchKernelGGL(fdtd2d_halo_deep, dim3((a.nx + 255) / 256, 2 * 7 * a.depth), dim3(256), 0, S(stream), a);
+}
+
+void launch_expand_codes(const ExpandCodes &a, void *stream)
+{
+    const unsigned xblocks = (unsigned)((a.nx + 1023) / 1024);
+    // at most 2^31 blocks per launch: planes go in groups
+    const long lines_per_launch = std::max<long>(a.rows, (long)(0x7fffffffL / xblocks) / a.rows * a.rows);
+    const long total = (long)a.rows * a.planes;
+    for (long first = 0; first < total; first += lines_per_launch) {
+        ExpandCodes b = a;
+        const long lines = std::min(lines_per_launch, total - first);
+        b.base = a.base + (size_t)(first / a.rows) * a.by * a.bx;
+        b.code = a.code + (size_t)(first / a.rows) * a.plane_pitch;
+        b.planes = (int)(lines / a.rows);
+        hipLaunchKernelGGL(fdtd_expand_codes, dim3((unsigned)(lines * xblocks)), dim3(256), 0, S(stream), b, xblocks);
+    }
 }
 
 void launch_probe2d(const Probe2D &a, void *stream)

@@ -134,7 +134,9 @@ void fdtd_destroy(fdtd_ctx *ctx);
  * `<pgm_dir>/v1_%05d.pgm`, nx*ny tokens read in sequence.  first_slice is the
  * 1-based index of the slice for z = 0 (the reference always uses 1);
  * upsample >= 1 repeats each PGM pixel upsample x upsample times in x and y
- * (nearest neighbour; 1 = the reference behaviour). */
+ * (nearest neighbour; 1 = the reference behaviour); with upsample > 1 the
+ * slice images go to the device as read and a kernel expands them into the
+ * per-cell code map. */
 int fdtd_load_materials(fdtd_ctx *ctx, const char *specs_path, const char *pgm_dir,
                         int first_slice, int upsample);
 /* The two halves of loadMaterials on caller data: one table row per material
@@ -146,7 +148,10 @@ int fdtd_set_codes(fdtd_ctx *ctx, const uint8_t *codes, size_t count);
 int fdtd_set_rp(fdtd_ctx *ctx, int face, const float *data, size_t count);
 int fdtd_get_rp(fdtd_ctx *ctx, int face, float *data, size_t count);
 /* setupMurBoundary (fdtd.cu:942-1024) evaluated on the materials now loaded
- * (opt-in: the reference only ever evaluates it on the defaults). */
+ * (opt-in: the reference only ever evaluates it on the defaults).  A slab
+ * fills in the entries of the cells it holds, which are the only ones its Mur
+ * updates read; the other entries of its planes keep the default-derived
+ * values (fdtd_get_rp returns them as such). */
 int fdtd_setup_mur_from_materials(fdtd_ctx *ctx);
 
 /* ---- time stepping ---------------------------------------------------- */

@@ -153,6 +153,30 @@ def test_2d_upsampled_pgm_matches_oracle_on_repeated_codes(oracle):
     assert util.run_and_compare(s, o, 300, 100, "upsampled PGM") == 0
 
 
+def test_3d_upsampled_pgm_slices_expanded_on_the_device(oracle, tmp_path):
+    """loadMaterials with upsample 3 in 3-D: every slice file is read as a (nx/3) x (ny/3) image and
+    repeated 3 x 3 times by a kernel; the oracle gets the repeated codes from numpy."""
+    bx, by, nz, u = 9, 7, 6, 3
+    nx, ny = bx * u, by * u
+    rng = np.random.default_rng(31)
+    base = rng.choice([0, 1, 45, 48, 94], size=(nz, by, bx)).astype(np.uint8)
+    for iz in range(nz):
+        (tmp_path / f"v1_{iz + 3:05d}.pgm").write_text(
+            f"P2\n# test\n{bx} {by}\n94\n" + "\n".join(str(c) for c in base[iz].ravel()) + "\n")
+    src = [(nx // 2, ny // 2, nz // 2)]
+    s = fdtd_amd.Solver(fdtd_amd.make_params(nx, ny, nz, src), ecoef=CON, kernel=B.KERNEL_FUSED)
+    o = oracle.Oracle(oracle.make_params(nx, ny, nz, src), ecoef=CON)
+    specs = os.path.join(DATA, "mat_specs_riken")
+    s.load_materials(specs, str(tmp_path), first_slice=3, upsample=u)
+    table, _ = B.read_material_specs(specs)
+    o.set_materials(np.repeat(np.repeat(base, u, axis=1), u, axis=2), table)
+    s.setup_mur_from_materials()
+    o.setup_mur()
+    for face in range(6):
+        assert np.array_equal(s.rp(face), o.rp(face)), face
+    assert util.run_and_compare(s, o, 40, 20, "3-D upsampled PGM") == 0
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_2d_multi_step_random_cases(oracle, seed):
     """Seeded random cases of the multi-step sweep: grid size (strip and band edges included),

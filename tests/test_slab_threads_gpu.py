@@ -148,6 +148,46 @@ def test_3d_slabs_on_threads_equal_oracle(oracle, monkeypatch, kernel, overlap):
         group.close()
 
 
+@pytest.mark.parametrize("dims,kernel", [((44, 23, 31), B.KERNEL_FUSED), ((300, 90, 1), MS3), ((300, 90, 1), B.KERNEL_FUSED)])
+def test_rp_planes_from_loaded_materials_per_slab(oracle, monkeypatch, dims, kernel):
+    """fdtd_setup_mur_from_materials on slabs: every slab derives the rp entries of the cells it
+    holds (the only ones its Mur launches read); the run equals the oracle with setupMurBoundary
+    evaluated on the whole loaded grid."""
+    nx, ny, nz = dims
+    world, steps = 3, 36
+    rng = np.random.default_rng(23)
+    codes = rng.integers(0, len(TABLE), size=(nz, ny, nx) if nz > 1 else (ny, nx), dtype=np.uint8)
+    srcs = [(nx // 2, ny // 2, nz // 2), (3, 3, 0 if nz == 1 else 2)]
+    slabs, parts, group = build_slabs(monkeypatch, dims, srcs, kernel, world, True, codes, default_slab=-1)
+    try:
+        if kernel == MS3:
+            # a multi-step slab recomputes its neighbours' boundary rows, Mur included, and does not
+            # hold their materials on the host: it says so
+            with pytest.raises(fdtd_amd.FdtdError, match="multi-step"):
+                slabs[0].setup_mur_from_materials()
+            return
+        for sv in slabs:
+            sv.setup_mur_from_materials()
+
+        def rank(r):
+            slabs[r].step(steps)
+            slabs[r].sync()
+
+        run_ranks(rank, world)
+        o = oracle.Oracle(oracle.make_params(nx, ny, nz, srcs, **DEFAULTS), ecoef=CON)
+        o.set_materials(codes if nz > 1 else codes[None], TABLE)
+        o.setup_mur()
+        assert len(set(np.round(o.rp(0), 3))) > 2          # the planes really vary
+        o.step(steps, threads=8)
+        for fid in util.fields_of(slabs[0]):
+            got = np.concatenate([sv.field(fid) for sv in slabs], axis=0 if nz > 1 else 1)
+            util.assert_bits_equal(got, np.asarray(o.field(fid)), B.FIELD_NAMES[fid])
+    finally:
+        for sv in slabs:
+            sv.close()
+        group.close()
+
+
 def test_multi_step_slab_without_a_communicator_refuses_to_outrun_its_halos():
     s = fdtd_amd.Solver(fdtd_amd.make_params(300, 100, 1, [(150, 50, 0)]), ecoef=CON, kernel=MS3, slab=(0, 50))
     s.step(3)

@@ -156,6 +156,7 @@ struct fdtd_ctx {
     // MULTISTEP slabs: deep halos (tb_steps rows of every live array per side)
     float *halo_send[2] = {}, *halo_recv[2] = {};
     bool auto_kernel = false;
+    bool interleave3 = false; // 3-D: the three components of a field share one allocation, row by row
     bool halo_stale = true; // set by everything that changes the state behind the stepper's back
     bool deep() const { return kernel == FDTD_KERNEL_MULTISTEP; }
     size_t deep_count() const { return (size_t)6 * tb_steps * nx + ((size_t)tb_steps * nx + 3) / 4; }
@@ -220,6 +221,7 @@ Grid3D grid3d(const fdtd_ctx *c)
     g.gz0 = c->s0;
     g.gnz = c->gn;
     g.pitch = c->pitch;
+    g.rowlen = c->cpitch;
     g.dt = p.dt;
     g.kh_x = p.dt / (p.mu0 * p.dx);
     g.kh_y = p.dt / (p.mu0 * p.dy);
@@ -312,7 +314,7 @@ int upload_codes(fdtd_ctx *c)
 {
     // owned rows only; halo rows keep the default code (their E is never updated here)
     const size_t rows = c->is2d() ? (size_t)c->sn : (size_t)c->sn * c->ny;
-    uint8_t *dst = c->code + (c->is2d() ? (size_t)c->cpitch : (size_t)c->ny * c->pitch);
+    uint8_t *dst = c->code + (c->is2d() ? (size_t)c->cpitch : (size_t)c->ny * c->cpitch);
     std::vector<uint8_t> dev(c->codes_host.size());
     int top = 0;
     for (size_t i = 0; i < dev.size(); ++i) {
@@ -320,7 +322,7 @@ int upload_codes(fdtd_ctx *c)
         top = std::max(top, (int)dev[i]);
     }
     c->ntab = top + 1;
-    HIPCHK(hipMemcpy2DAsync(dst, c->is2d() ? c->cpitch : c->pitch, dev.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice,
+    HIPCHK(hipMemcpy2DAsync(dst, c->cpitch, dev.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice,
                             c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -432,10 +434,11 @@ int exchange_halos(fdtd_ctx *c, hipStream_t st, bool scan)
         }
         return 0;
     }
+    // (interleaved components: the plane of ex, ey and ez is one run of memory, one message)
     const size_t count = c->is2d() ? (size_t)c->nx : (size_t)c->ny * c->pitch;
-    const int c0 = c->is2d() ? 2 : 0;
+    const int c0 = c->is2d() ? 2 : 0, c1 = c->interleave3 ? 1 : 3;
     int rc = comm_group_start(c->comm);
-    for (int comp = c0; comp < 3 && rc == 0; ++comp) {
+    for (int comp = c0; comp < c1 && rc == 0; ++comp) {
         if (lower >= 0) {
             rc = comm_send(c->comm, halo_rows(c, comp, 0, false), count, lower, st);
             if (rc == 0) rc = comm_recv(c->comm, halo_rows(c, comp, 0, true), count, lower, st);
@@ -617,7 +620,7 @@ int step_once(fdtd_ctx *c)
             f.ntab = c->ntab;
             f.jz = a.src.jz;
             f.nsrc = a.src.count;
-            const long long p4 = c->pitch / 4;
+            const long long p4 = c->cpitch / 4;
             f.plane_words = (long long)c->ny * p4;
             // wave-aligned segments: the last lane of a segment is lane 63 of its wave
             f.seg_words = (int)(((f.plane_words + 7) / 8 + 63) / 64 * 64);
@@ -993,12 +996,16 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     // apart, which is what DRAM pages want (16384^2: FDTD_TB_INTERLEAVE=0 gives the separate arrays).
     bool interleave = c->kernel == FDTD_KERNEL_MULTISTEP;
     if (const char *v = std::getenv("FDTD_TB_INTERLEAVE")) interleave = interleave && std::atoi(v) != 0;
-    c->pitch = interleave ? 6 * row_pitch : row_pitch;
+    // Fused 3-D sweep: the three components of a field are interleaved row by row (row y of ex, of ey,
+    // of ez, then row y + 1 ...): 8 runs of memory per sweep instead of 24 (FDTD_3D_INTERLEAVE=0: apart).
+    c->interleave3 = !c->is2d() && c->kernel == FDTD_KERNEL_FUSED;
+    if (const char *v = std::getenv("FDTD_3D_INTERLEAVE")) c->interleave3 = c->interleave3 && std::atoi(v) != 0;
+    c->pitch = interleave ? 6 * row_pitch : c->interleave3 ? 3 * row_pitch : row_pitch;
     c->cpitch = row_pitch;
     c->rows_store = c->is2d() ? (size_t)c->sn + 2 * c->halo : ((size_t)c->sn + 2) * c->ny;
     c->elems = c->rows_store * c->pitch;
     c->lead = (size_t)(c->halo - 1) * c->pitch;
-    c->celems = c->rows_store * (c->is2d() ? (size_t)c->cpitch : (size_t)c->pitch);
+    c->celems = c->rows_store * (size_t)c->cpitch;
     c->clead = (size_t)(c->halo - 1) * c->cpitch;
 
     int rc = 0;
@@ -1014,6 +1021,16 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             c->e[2][2 * grp + 1] = first + 3 * (size_t)row_pitch;
             c->d[2][2 * grp] = first + 4 * (size_t)row_pitch;
             c->d[2][2 * grp + 1] = first + 5 * (size_t)row_pitch;
+        }
+    } else if (c->interleave3) {
+        // groups of three: H (two generations), E and D (two levels each)
+        float **groups[6] = {&c->h[0][0], &c->h[0][1], &c->e[0][0], &c->e[0][1], &c->d[0][0], &c->d[0][1]};
+        const size_t comp_step[6] = {2, 2, 4, 4, 4, 4}; // elements between [k][i] and [k + 1][i] of h[3][2], e[3][4], d[3][4]
+        for (int grp = 0; grp < 6 && !rc; ++grp) {
+            float *base = nullptr;
+            if ((rc = dev_alloc(c, &base, c->elems + 2 * kSlack))) break;
+            c->state_bufs.push_back({base + kSlack, c->elems});
+            for (int k = 0; k < 3; ++k) groups[grp][k * comp_step[grp]] = base + kSlack + c->lead + (size_t)k * row_pitch;
         }
     } else {
         const bool two_h = c->one_pass();
@@ -1174,7 +1191,7 @@ int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir
         hipError_t e = hipMemcpyAsync(dbase, dev.data(), dev.size(), hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             ExpandCodes x;
-            x.code = c->code + (c->is2d() ? (size_t)c->cpitch : (size_t)c->ny * c->pitch);
+            x.code = c->code + (c->is2d() ? (size_t)c->cpitch : (size_t)c->ny * c->cpitch);
             x.base = dbase;
             x.nx = c->nx;
             x.bx = bx;
@@ -1183,8 +1200,8 @@ int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir
             x.rows = c->is2d() ? c->sn : c->ny;
             x.row0 = c->is2d() ? c->s0 : 0;
             x.planes = planes;
-            x.row_pitch = c->is2d() ? c->cpitch : c->pitch;
-            x.plane_pitch = c->is2d() ? 0 : (long long)c->ny * c->pitch;
+            x.row_pitch = c->cpitch;
+            x.plane_pitch = c->is2d() ? 0 : (long long)c->ny * c->cpitch;
             launch_expand_codes(x, c->stream);
             e = hipGetLastError();
         }
@@ -1370,7 +1387,7 @@ int fdtd_sweep_work(const fdtd_ctx *c, int64_t *waves, int64_t *row_iterations)
     if (!c->deep()) {
         // one-step kernels: a wave handles one row (2-D: of 256 columns; 3-D: 64 words of a plane) once
         const int64_t w = c->is2d() ? (int64_t)((c->nx + 255) / 256) * c->sn
-                                    : ((int64_t)c->ny * (c->pitch / 4) + 63) / 64 * c->sn;
+                                    : ((int64_t)c->ny * (c->cpitch / 4) + 63) / 64 * c->sn;
         if (waves) *waves = w;
         if (row_iterations) *row_iterations = w;
         return 0;
@@ -1865,7 +1882,7 @@ int fdtd_comm_selftest(fdtd_ctx *c)
         return 0;
     }
     // first owned row of the newest E level -> upper halo row, through ncclSend/ncclRecv to this rank
-    const int comp = 2;
+    const int comp = c->interleave3 ? 0 : 2; // interleaved components: the run that starts at ex holds all three
     const size_t count = c->is2d() ? (size_t)c->nx : (size_t)c->ny * c->pitch;
     int rc = comm_group_start(c->comm);
     if (!rc) rc = comm_send(c->comm, halo_rows(c, comp, 0, false), count, c->rank, c->stream);

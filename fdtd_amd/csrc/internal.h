@@ -135,6 +135,8 @@ struct Mur2D {
 // local plane k = q - 1 (global gz0 + k); planes k = -1 and k = nzl are halos.
 struct Grid3D {
     int nx, ny, nzl, gz0, gnz, pitch;
+    int rowlen; // floats of one row (the code array's pitch in bytes); pitch = 3 * rowlen when the three
+                // components of a field are interleaved row by row, else rowlen
     float dt;
     float kh_x, kh_y, kh_z;
     float cx, cy, cz;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void fdtd3d_de(const Sweep3D a)
     const bool g_ex = x_in && y_lo && y_in && z_lo && z_in;
     const bool g_eyz = x_lo && z_lo;
     if (g_ex || g_eyz) {
-        const MatEntry m = a.table[a.code[o]];
+        const MatEntry m = a.table[a.code[((size_t)(k + 1) * g.ny + y) * g.rowlen + x]];
         if (g_ex) a.e_w[0][o] = e_update(m, g.dt, a.e_n[0][o], a.e_w[0][o], dn[0], d0[0], d1[0]);
         if (g_eyz) {
             a.e_w[1][o] = e_update(m, g.dt, a.e_n[1][o], a.e_w[1][o], dn[1], d0[1], d1[1]);

@@ -59,7 +59,7 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
     // Block ids are dealt to the 8 XCDs in turn.  XCD i (block id mod 8) owns segment i --
     // one eighth of the words -- of EVERY plane and walks the planes in z order, so the
     // lines of plane z-1 and z+1 it needs are the ones it pulled into its own L2 a plane ago.
-    const int p4 = g.pitch >> 2;
+    const int p4 = g.rowlen >> 2;
     const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
     const int k = a.k_begin + (int)(seq / (unsigned)a.seg_blocks);
     const unsigned in_seg = (seq % (unsigned)a.seg_blocks) * 256u + threadIdx.x;
@@ -71,24 +71,21 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
     const int z = g.gz0 + k;
     const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
     const size_t o = act ? (size_t)(k + 1) * ps + (size_t)y * rs + x4 : ps;
+    const size_t co = act ? ((size_t)(k + 1) * g.ny + (size_t)y) * g.rowlen + x4 : 0; // code array: rows of rowlen bytes
 
     const float *ex = a.e_n[0], *ey = a.e_n[1], *ez = a.e_n[2];
     const float *hx = a.h_r[0], *hy = a.h_r[1], *hz = a.h_r[2];
 
-    // Material codes first, and the table rows they select right behind them: a chain of two
-    // dependent loads that would otherwise start only after the 31 field loads have come back.
-    const unsigned cd = act ? *(const unsigned *)(a.code + o) : 0u;
+    // Material codes first, and for a wave that holds one material the table row right behind
+    // them: a chain of two dependent loads that would otherwise start only after the field loads
+    // have come back.  (A mixed wave gathers its rows next to the E update: they stay in cache.)
+    const unsigned cd = act ? *(const unsigned *)(a.code + co) : 0u;
     bool uniform = true;
-    MatEntry mu = a.one, mm[4];
+    MatEntry mu = a.one;
     if (!ONE) {
         const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cd) & 0xffu;
         uniform = __all(cd == c0 * 0x01010101u);
-        if (uniform) {
-            mu = a.table[c0];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) mm[i] = a.table[(cd >> (8 * i)) & 0xffu];
-        }
+        if (uniform) mu = a.table[c0];
     }
 
     // E^n and old H: own row and the rows below in y and z (and the two diagonals)
@@ -101,13 +98,6 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
     const f4 hx_c = ld4(hx + o, act, false), hx_my = ld4(hx + o - rs, act, false), hx_mz = ld4(hx + o - ps, act, true);
     const f4 hy_c = ld4(hy + o, act, false), hy_mz = ld4(hy + o - ps, act, true);
     const f4 hz_c = ld4(hz + o, act, false), hz_my = ld4(hz + o - rs, act, true);
-    f4 d0[3], d1[3], e1[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        d0[c] = ld4(a.d_n[c] + o, act, true);
-        d1[c] = ld4(a.d_w[c] + o, act, true);
-        e1[c] = ld4(a.e_w[c] + o, act, true);
-    }
 
     // scalars the lanes at the two ends of the wave lack
     const bool edge_r = (lane == 63) && act && (x4 + 4 < g.nx);
@@ -179,6 +169,18 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
     const f4 hy_nx = shift_right(hy_n, lane, e_hy);
     const f4 hz_nx = shift_right(hz_n, lane, e_hz);
 
+    // The nine pointwise-only words (D^n, D^{n-1}, E^{n-1}) are loaded here, behind the H arithmetic
+    // that retires most of the 22 stencil words: fewer registers are live at once, three waves fit
+    // a SIMD instead of two and cover each other's waits (512^3: 2.49 ms per sweep against 2.82).
+    __builtin_amdgcn_sched_barrier(0);
+    f4 d0[3], d1[3], e1[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        d0[c] = ld4(a.d_n[c] + o, act, true);
+        d1[c] = ld4(a.d_w[c] + o, act, true);
+        e1[c] = ld4(a.e_w[c] + o, act, true);
+    }
+
     // sources of this word
     unsigned srcflag = 0;
     for (int s = 0; s < a.nsrc; ++s)
@@ -203,7 +205,7 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         MatEntry m = mu;
-        if (!ONE && !uniform) m = mm[i];
+        if (!ONE && !uniform) m = a.table[(cd >> (8 * i)) & 0xffu];
         const bool g_ex = x_hi[i] && y_lo && y_hi && z_lo && z_hi;
         const bool g_eyz = x_lo[i] && z_lo;
         en[0][i] = g_ex ? e_update(m, g.dt, ex_c[i], e1[0][i], dn[0][i], d0[0][i], d1[0][i]) : e1[0][i];
@@ -228,13 +230,14 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
     }
 }
 
+
 } // namespace
 
 void launch_sweep3d(const Fused3D &a, void *stream)
 {
     if (a.k_end <= a.k_begin) return;
     const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)(a.k_end - a.k_begin));
-    static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 2;
+    static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 3;
 #define GO(W)                                                                                     \
     do {                                                                                          \
         if (a.ntab == 1)                                                                          \
@@ -242,12 +245,10 @@ void launch_sweep3d(const Fused3D &a, void *stream)
         else                                                                                      \
             hipLaunchKernelGGL((fdtd3d_sweep<false, W>), grid, dim3(256), 0, (hipStream_t)stream, a); \
     } while (0)
-    if (waves == 3)
-        GO(3);
-    else if (waves == 4)
-        GO(4);
-    else
+    if (waves == 2)
         GO(2);
+    else
+        GO(3);
 #undef GO
 }
 

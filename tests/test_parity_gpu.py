@@ -77,6 +77,30 @@ def test_3d_mur_from_loaded_materials(oracle):
     assert util.run_and_compare(s, o, 30, 10, "rp from materials") == 0
 
 
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, B.KERNEL_SPLIT])
+def test_3d_body_slices_at_full_plane_size(oracle, kernel):
+    """The plane size the reference data has (265 x 490, pitch 272: rows that are no multiple of a
+    wave, XCD segments that cut rows), 24 planes of the tissue slice v1_00800 with a different
+    tissue swapped in on every third plane, mat_specs_riken, rp planes from the loaded materials,
+    sources next to faces: every field against the oracle bit for bit."""
+    nx, ny, nz, steps = 265, 490, 24, 10
+    srcs = [(40, 245, 12), (1, 1, 0), (264, 489, 23), (130, 200, 1)]
+    s, o = util.pair(oracle, (nx, ny, nz), srcs, CON, kernel=kernel)
+    specs = os.path.join(DATA, "mat_specs_riken")
+    table, present = B.read_material_specs(specs)
+    base = B.read_pgm_codes(os.path.join(DATA, "pgmdata", "v1_00800.pgm"), nx, ny)
+    codes = np.broadcast_to(base, (nz, ny, nx)).copy()
+    codes[::3][codes[::3] == 48] = 45
+    for code in np.flatnonzero(present):
+        s.set_material(int(code), *[float(v) for v in table[code]])
+    s.set_codes(codes)
+    o.set_materials(codes, table)
+    s.setup_mur_from_materials()
+    o.setup_mur()
+    assert util.run_and_compare(s, o, steps, 5, "3-D body slices") == 0
+    assert np.abs(s.field(B.EX)).max() > 0
+
 # ------------------------------------------------------------------ 2-D TMz
 
 MS2, MS3, MS4, MS5, MS6, MS7, MS8 = [(B.KERNEL_MULTISTEP, k) for k in (2, 3, 4, 5, 6, 7, 8)]

@@ -27,6 +27,8 @@
 // Materials.  A wave whose 256 cells hold one material code takes that
 // material's four coefficients through scalar loads; a mixed wave gathers one
 // 16-byte table row per cell (the table stays in L1/L2).
+#include <cstdlib>
+
 #include "device_math.h"
 
 namespace fdtd {
@@ -77,8 +79,8 @@ struct BlockMap {
 };
 
 // ONE: the whole grid is one material; its coefficients are a kernel argument.
-template <bool ONE, int POL>
-__global__ __launch_bounds__(256) void fdtd2d_sweep(const Sweep2D a, const BlockMap m)
+template <bool ONE, int POL, int W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(W, W))) void fdtd2d_sweep(const Sweep2D a, const BlockMap m)
 {
     const Grid2D &g = a.g;
     const int lane = threadIdx.x & 63;
@@ -244,17 +246,27 @@ void launch_sweep2d(const Sweep2D &a, void *stream)
         nblocks = (unsigned)((xblocks.chunks + a.band - 1) / a.band) * (unsigned)a.band * (unsigned)xblocks.xblocks;
     const dim3 grid(nblocks);
     const bool one = a.ntab == 1;
-    if (a.variant & 1) {
-        if (one)
-            hipLaunchKernelGGL((fdtd2d_sweep<true, 1>), grid, dim3(256), 0, (hipStream_t)stream, a, xblocks);
-        else
-            hipLaunchKernelGGL((fdtd2d_sweep<false, 1>), grid, dim3(256), 0, (hipStream_t)stream, a, xblocks);
-    } else {
-        if (one)
-            hipLaunchKernelGGL((fdtd2d_sweep<true, 0>), grid, dim3(256), 0, (hipStream_t)stream, a, xblocks);
-        else
-            hipLaunchKernelGGL((fdtd2d_sweep<false, 0>), grid, dim3(256), 0, (hipStream_t)stream, a, xblocks);
-    }
+    // Waves per SIMD are pinned: more waves widen the band of rows in flight and DRAM serves a
+    // compact band fastest (16384^2: 2 waves 1.885 ms, 3 1.794, 4 1.829, 5 1.925 per sweep).
+    static const int waves = std::getenv("FDTD_SWEEP2D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP2D_WAVES")) : 3;
+#define GO(POL, W)                                                                                          \
+    do {                                                                                                    \
+        if (one)                                                                                            \
+            hipLaunchKernelGGL((fdtd2d_sweep<true, POL, W>), grid, dim3(256), 0, (hipStream_t)stream, a, xblocks);  \
+        else                                                                                                \
+            hipLaunchKernelGGL((fdtd2d_sweep<false, POL, W>), grid, dim3(256), 0, (hipStream_t)stream, a, xblocks); \
+    } while (0)
+    if (!(a.variant & 1))
+        GO(0, 3);
+    else if (waves == 5)
+        GO(1, 5);
+    else if (waves == 4)
+        GO(1, 4);
+    else if (waves == 2)
+        GO(1, 2);
+    else
+        GO(1, 3);
+#undef GO
 }
 
 const char *sweep2d_kernel_name() { return "fdtd2d_sweep"; }

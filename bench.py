@@ -5,14 +5,22 @@ One "step" is one full time step (H, D, source, E, Mur) of one slab.  At
 --gpus 1 the workload is BASELINE.json's configs[1]: a 16384 x 16384 2-D TMz
 grid, vacuum, one point source at the centre.  At --gpus N every rank holds a
 16384 x 16384 slab of a 16384 x (16384*N) grid (weak scaling) and exchanges halo
-rows with each neighbour over RCCL (once per pass of the multi-step sweep: four
-rows of every array; once per step, one ez row, with the one-step kernels).  The metric is
+rows with each neighbour over RCCL on a second stream, beside the sweep of the
+interior rows (once per pass of the multi-step sweep: eight rows of every array;
+once per step, one ez row, with the one-step kernels).  The metric is
 Mcell-updates/s = cells * steps / seconds / 1e6, whole job.
 
-Prints one JSON line (rank 0) with the roofline of the dominant kernel (HBM
-bound; 41 algorithmic bytes per 2-D cell-update) measured with HIP events on
-the library's stream, and -- at one GPU -- the CPU oracle timed on the host
-cores on a bounded sample of the same workload.
+Prints one JSON line (rank 0):
+  roofline           the dominant kernel (HBM bound), timed with HIP events on the library's
+                     stream: `achieved` = algorithmic bytes of ONE launch / its average duration.
+                     A pass of the multi-step sweep moves every live array once whatever the
+                     number of steps it advances: 49 B per cell (25 in, 24 out); only launches
+                     that advanced the full steps_per_pass are averaged, `launches` lists all.
+                     `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
+                     (profiles/traffic.json); `one_step_equivalent` prices the same cell-updates
+                     at the 41 B a one-step sweep moves; `issue_bound` is a vector-issue estimate.
+  roofline_one_step  (one GPU, 2-D) the one-step sweep on the same workload: 41 B per cell-update.
+  cpu_baseline       (one GPU) the CPU oracle on the host cores, on a bounded sample.
 """
 import argparse
 import json
@@ -278,6 +286,7 @@ def main():
             if done % args.snapshot_every == 0:
                 solver.snapshot_async(B.EZ)            # waits for the previous one, then queues the next
                 snapshots += 1
+        solver.sync()                                  # the steps are done: what is left is the last D2H
         t_tail = time.perf_counter()
         solver.snapshot_wait()
         tail_ms = (time.perf_counter() - t_tail) * 1e3

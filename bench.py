@@ -130,7 +130,7 @@ def main():
     ap.add_argument("--ny", type=int, default=16384, help="rows per GPU")
     ap.add_argument("--nz", type=int, default=1, help="> 1 selects the 3-D path (z planes per GPU)")
     ap.add_argument("--chunk-rows", type=int, default=0)
-    ap.add_argument("--kernel", choices=["auto", "split", "fused", "multistep"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "split", "fused", "multistep", "tile"], default="auto")
     ap.add_argument("--steps-per-pass", type=int, default=0, help="multistep kernel: time steps per pass (2..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device", type=int, default=-1, help="GPU ordinal (default: LOCAL_RANK)")
@@ -203,7 +203,7 @@ def main():
         bytes_per_cell = BYTES_PER_CELL_2D
     params = fdtd_amd.make_params(*gdims, src)
     kernel = {"auto": B.KERNEL_AUTO, "split": B.KERNEL_SPLIT, "fused": B.KERNEL_FUSED,
-              "multistep": B.KERNEL_MULTISTEP}[args.kernel]
+              "multistep": B.KERNEL_MULTISTEP, "tile": B.KERNEL_TILE}[args.kernel]
     if world > 1 and kernel == B.KERNEL_AUTO:
         # every rank must run the same kernel with the same halo depth: say so instead of leaving
         # it to each rank's own decision

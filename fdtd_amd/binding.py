@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 MAX_SOURCES, MAX_JZ, MAX_CODES, MAX_PROBES = 16, 512, 256, 16
 MODE_AUTO, MODE_3D, MODE_2D_TMZ = 0, 1, 2
 ECOEF_REFERENCE, ECOEF_CONSISTENT = 0, 1
-KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MULTISTEP = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_SPLIT, KERNEL_FUSED, KERNEL_MULTISTEP, KERNEL_TILE = 0, 1, 2, 3, 4
 HX, HY, HZ, DX, DY, DZ, EX, EY, EZ = range(9)
 FIELD_NAMES = ["hx", "hy", "hz", "dx", "dy", "dz", "ex", "ey", "ez"]
 DEFAULT_CODE = 255

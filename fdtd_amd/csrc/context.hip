@@ -104,6 +104,7 @@ struct fdtd_ctx {
     int hgen = 0; // index of the newest H generation
     int tb_steps = 1;  // MULTISTEP: time steps per pass (also the halo depth in rows)
     int tb_rows = 32;  // MULTISTEP: owned rows per wave
+    bool tile = false; // MULTISTEP storage and schedule, tiled sweep (sweep2d_tile.hip): small grids
     int tb_map = 0;    // MULTISTEP: 1 = every XCD walks its own panel of strips (16384^2: 4.47 ms per pass against 3.42)
     int halo = 1;      // halo rows (2-D) on either side of the slab
     size_t lead = 0;   // floats between the start of an array and local row -1: (halo - 1) * pitch
@@ -348,7 +349,7 @@ float *halo_rows(fdtd_ctx *c, int comp, int side, bool halo)
     return base + row * unit;
 }
 
-void record_probes(fdtd_ctx *c, int mid);
+void record_probes(fdtd_ctx *c, int mid, bool launch = true);
 
 int ensure_deep_buffers(fdtd_ctx *c)
 {
@@ -673,11 +674,13 @@ int step_once(fdtd_ctx *c)
 
 // Appends the newest step to the probe ring.  `mid` > 0: the `mid` steps before it were written
 // by the multi-step sweep for the probes this slab holds; the others get their zeros here.
-void record_probes(fdtd_ctx *c, int mid)
+void record_probes(fdtd_ctx *c, int mid, bool launch)
 {
     if (c->probes.count > 0 && c->probe_ring) {
         const int slot = (int)((c->step - 1) % c->probe_cap);
-        if (c->is2d()) {
+        if (!launch) {
+            // the sweep has written the rows itself
+        } else if (c->is2d()) {
             Probe2D q;
             q.g = grid2d(c);
             q.hx = c->h[0][c->hgen];
@@ -725,7 +728,10 @@ void tb_rows_of(const fdtd_ctx *c, SweepTB &a, int y_begin, int y_end)
     a.tail_begin = tail > 0 ? y_begin + a.big_bands * c->tb_rows : y_end;
 }
 
-// MULTISTEP: K <= tb_steps time steps in one pass (sweep2d_tb.hip), then Mur on the newest level.
+int finish_pass(fdtd_ctx *c, const SweepTB &a, int K, const Split &sp, int lo, int hi, bool tail);
+
+// MULTISTEP: K <= tb_steps time steps in one pass (sweep2d_tb.hip), then Mur on the newest level;
+// the tiled sweep (sweep2d_tile.hip) does all of it in one launch.
 int pass_once(fdtd_ctx *c, int K)
 {
     int rc = snapshot_guard(c);
@@ -775,6 +781,35 @@ int pass_once(fdtd_ctx *c, int K)
     const int edge = (c->tb_steps + 15) / 16 * 16;
     const Split sp = split_of(c, edge, c->tb_rows);
     const int lo = sp.on && sp.lower ? edge : 0, hi = sp.on && sp.upper ? c->sn - edge : c->sn;
+    if (c->tile) {
+        SweepTile t;
+        t.b = a;
+        t.steps = K;
+        t.halo_rows = c->halo;
+        t.slot_last = a.ring ? (int)((c->step + K - 1) % c->probe_cap) : 0;
+        t.own_rows = t.tiles_x = 0;
+        bool bad = false;
+        if (sp.on) {
+            if ((rc = fork_xstream(c))) return rc;
+            const int ranges[2][2] = {{0, lo}, {hi, c->sn}};
+            for (const auto &r : ranges) {
+                if (r[1] <= r[0]) continue;
+                t.b.y_begin = r[0];
+                t.b.y_end = r[1];
+                bad |= launch_sweep2d_tile(t, c->xstream) != 0;
+            }
+        }
+        t.b.y_begin = lo;
+        t.b.y_end = hi;
+        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
+        bad |= launch_sweep2d_tile(t, c->stream) != 0;
+        if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
+        if (bad) {
+            set_error("the tiled sweep cannot run this pass (steps per pass outside 1 .. 8)");
+            return -3;
+        }
+        return finish_pass(c, a, K, sp, lo, hi, false);
+    }
     if (sp.on) {
         if ((rc = fork_xstream(c))) return rc;
         SweepTB e = a;
@@ -795,10 +830,32 @@ int pass_once(fdtd_ctx *c, int K)
         return -3;
     }
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
+    return finish_pass(c, a, K, sp, lo, hi, true);
+}
+
+// What follows the sweep launches of a pass: the roles of the arrays swap, Mur on the newest level
+// and the probe rows (`tail`: as launches of their own; the tiled sweep has done both itself), the
+// halo exchange.
+int finish_pass(fdtd_ctx *c, const SweepTB &a, int K, const Split &sp, int lo, int hi, bool tail)
+{
+    int rc;
+    const bool prof = c->prof_n < c->prof_cap;
     c->pair ^= 1;
     c->cur = 1;
     c->hgen ^= 1;
     c->step += K;
+    if (!tail) {
+        HIPCHK(hipGetLastError());
+        if (prof) c->prof_steps[c->prof_n++] = K;
+        if (sp.on) {
+            if ((rc = exchange_halos(c, c->xstream, false))) return rc;
+            if ((rc = join_xstream(c))) return rc;
+        } else if ((rc = exchange_halos(c, c->stream, false))) {
+            return rc;
+        }
+        record_probes(c, K - 1, false);
+        return 0;
+    }
 
     Mur2D m = mur2d_args(c, a.g, c->E(2, 0), c->E(2, 1));
     if (sp.on) {
@@ -895,7 +952,14 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         // its row-by-row march, not by bandwidth, and the one-step sweep is as fast or faster
         // (measured crossover: 2048^2).  Decided from the extents of the WHOLE grid, so that every
         // slab of it takes the same kernel.
-        c->kernel = (c->is2d() && (double)p->nx * (double)p->ny >= 6e6) ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_FUSED;
+        // Smaller 2-D grids are bound by launch and memory latency: the tiled sweep advances them
+        // several steps per launch out of registers and LDS.
+        c->kernel = !c->is2d() ? FDTD_KERNEL_FUSED : (double)p->nx * (double)p->ny >= 6e6 ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_TILE;
+    }
+    if (c->kernel == FDTD_KERNEL_TILE) {
+        // the storage, the schedule and the halo protocol of the multi-step mode, another sweep kernel
+        c->tile = true;
+        c->kernel = FDTD_KERNEL_MULTISTEP;
     }
     if (c->kernel != FDTD_KERNEL_SPLIT && c->kernel != FDTD_KERNEL_FUSED && c->kernel != FDTD_KERNEL_MULTISTEP) {
         set_error("unknown kernel selection");
@@ -903,17 +967,17 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP) {
         if (!c->is2d()) {
-            set_error("FDTD_KERNEL_MULTISTEP exists for the 2-D TMz mode only");
+            set_error("FDTD_KERNEL_MULTISTEP and FDTD_KERNEL_TILE exist for the 2-D TMz mode only");
             return -3;
         }
         // (4096^2: 270 Gcell-updates/s at 6 steps per pass, 252 at 8; 8192^2: 422 against 448);
         // from the extents of the whole grid: every slab must advance the same number of steps
         // between two halo exchanges
         const bool mid = (double)p->nx * (double)p->ny < 48e6;
-        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : mid ? 6 : kDefaultStepsPerPass;
+        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : (mid && !c->tile) ? 6 : kDefaultStepsPerPass;
         c->spp_fixed = opt->steps_per_pass > 0 || (opt->slab_count > 0 && opt->slab_count != p->ny);
-        if (c->tb_steps < 2 || c->tb_steps > kMaxStepsPerPass) {
-            set_error("steps_per_pass must be 2 .. 8");
+        if (c->tb_steps < (c->tile ? 1 : 2) || c->tb_steps > kMaxStepsPerPass) {
+            set_error("steps_per_pass must be 2 .. 8 (FDTD_KERNEL_TILE: 1 .. 8)");
             return -3;
         }
         c->tb_rows = 0; // chosen once the slab is known
@@ -1322,7 +1386,7 @@ int fdtd_step(fdtd_ctx *c, int nsteps)
     for (int i = 0; i < nsteps;) {
         // full passes, then one shorter pass for the remainder (a single step: the one-step sweep)
         const int k = std::min(nsteps - i, spp);
-        int rc = k >= 2 ? pass_once(c, k) : step_once(c);
+        int rc = (k >= 2 || c->tile) ? pass_once(c, k) : step_once(c);
         if (rc) return rc;
         i += k;
     }
@@ -1335,7 +1399,7 @@ int fdtd_steps_per_pass(const fdtd_ctx *c)
     // Several materials on a whole grid: 7 steps per pass with four waves per workgroup beat 8 with
     // three.  Slabs keep the number they were created with: every rank must advance the same
     // number of steps between two exchanges whatever materials it holds.
-    if (c->spp_fixed || c->ntab_eff() == 1) return c->tb_steps;
+    if (c->spp_fixed || c->tile || c->ntab_eff() == 1) return c->tb_steps;
     return std::min(c->tb_steps, kFastStepsPerPassTable);
 }
 
@@ -1384,6 +1448,14 @@ int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
 
 int fdtd_sweep_work(const fdtd_ctx *c, int64_t *waves, int64_t *row_iterations)
 {
+    if (c->tile) {
+        // one workgroup of 16 waves per tile of 48 x (64 - 2 * steps) owned cells, one iteration per step
+        const int K = c->tb_steps;
+        const int64_t tiles = (int64_t)(((c->nx + 3) / 4 + 11) / 12) * ((c->sn + 63 - 2 * K) / (64 - 2 * K));
+        if (waves) *waves = tiles * 16;
+        if (row_iterations) *row_iterations = tiles * 16 * K;
+        return 0;
+    }
     if (!c->deep()) {
         // one-step kernels: a wave handles one row (2-D: of 256 columns; 3-D: 64 words of a plane) once
         const int64_t w = c->is2d() ? (int64_t)((c->nx + 255) / 256) * c->sn
@@ -1406,7 +1478,7 @@ int fdtd_sweep_work(const fdtd_ctx *c, int64_t *waves, int64_t *row_iterations)
 
 const char *fdtd_sweep_kernel_name(const fdtd_ctx *c)
 {
-    if (c->is2d() && c->kernel == FDTD_KERNEL_MULTISTEP) return sweep2d_tb_kernel_name();
+    if (c->is2d() && c->kernel == FDTD_KERNEL_MULTISTEP) return c->tile ? sweep2d_tile_kernel_name() : sweep2d_tb_kernel_name();
     if (c->is2d()) return c->kernel == FDTD_KERNEL_FUSED ? sweep2d_kernel_name() : de2d_kernel_name();
     return c->kernel == FDTD_KERNEL_FUSED ? sweep3d_kernel_name() : de3d_kernel_name();
 }

@@ -121,6 +121,18 @@ struct SweepTB {
     int strips_per_xcd;                   // map 1: ceil(strips / 8)
 };
 
+// The tiled multi-step 2-D sweep (sweep2d_tile.hip): the arguments of a pass of the multi-step
+// sweep (b.rows, b.big_bands, b.tail_*, b.strips, b.map are not used; b.y_begin .. b.y_end are
+// the rows the launch covers) and the shape of the launch.
+struct SweepTile {
+    SweepTB b;
+    int steps;      // time steps this pass advances: 1 .. kMaxStepsPerPass
+    int halo_rows;  // halo rows the arrays hold on either side of the slab (>= steps)
+    int slot_last;  // probe ring slot of the last level (b.slot[] holds those of levels 1 .. steps-1)
+    int own_rows;   // rows a tile owns: tile height - 2 * steps (set by the launcher)
+    int tiles_x;    // tiles across a row (set by the launcher)
+};
+
 struct Mur2D {
     Grid2D g;
     int j_begin, j_end; // local rows this launch finishes (x-face cells of those rows, y faces that lie in them)
@@ -236,6 +248,9 @@ void launch_sweep2d(const Sweep2D &a, void *stream);
 // Returns 0, or -1 when no kernel exists for `steps`.
 int launch_sweep2d_tb(const SweepTB &a, int steps, void *stream);
 const char *sweep2d_tb_kernel_name();
+// Returns 0, or -1 when the pass cannot be tiled (steps outside 1 .. kMaxStepsPerPass, no rows).
+int launch_sweep2d_tile(const SweepTile &t, void *stream);
+const char *sweep2d_tile_kernel_name();
 void launch_sweep3d(const Fused3D &a, void *stream);
 void launch_mur2d(const Mur2D &a, void *stream);
 void launch_h3d(const Sweep3D &a, void *stream);

@@ -57,11 +57,16 @@ enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
  * the same arithmetic per cell and step, 16 more bytes of HBM per cell (E and D
  * keep four arrays instead of two).  fdtd_step(n) runs n / steps_per_pass
  * passes and the remainder as one shorter pass (a single step: FUSED).
- * AUTO: MULTISTEP for 2-D grids of 6 M cells or more (extents of the WHOLE
- * grid, so every slab of it decides alike), else FUSED; a whole grid whose
- * MULTISTEP arrays do not fit into device memory falls back to FUSED, a slab
- * reports the error. */
-enum { FDTD_KERNEL_AUTO = 0, FDTD_KERNEL_SPLIT = 1, FDTD_KERNEL_FUSED = 2, FDTD_KERNEL_MULTISTEP = 3 };
+ * TILE (2-D TMz only): storage, schedule and halo protocol of MULTISTEP, but a
+ * workgroup advances a tile of 64 columns x 64 (32) rows `steps_per_pass`
+ * steps out of registers and LDS and writes the Mur faces and the probe rows
+ * itself: ONE launch per pass, for grids that are bound by launch and memory
+ * latency instead of bandwidth.  steps_per_pass 1 .. 8.
+ * AUTO: 2-D grids of 6 M cells or more MULTISTEP, smaller ones TILE (extents of
+ * the WHOLE grid, so every slab of it decides alike), 3-D FUSED; a whole grid
+ * whose MULTISTEP arrays do not fit into device memory falls back to FUSED, a
+ * slab reports the error. */
+enum { FDTD_KERNEL_AUTO = 0, FDTD_KERNEL_SPLIT = 1, FDTD_KERNEL_FUSED = 2, FDTD_KERNEL_MULTISTEP = 3, FDTD_KERNEL_TILE = 4 };
 
 typedef struct fdtd_options {
     int32_t mode;        /* FDTD_MODE_*; AUTO = 2-D TMz when nz == 1 */

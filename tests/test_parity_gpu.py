@@ -104,7 +104,8 @@ def test_3d_body_slices_at_full_plane_size(oracle, kernel):
 # ------------------------------------------------------------------ 2-D TMz
 
 MS2, MS3, MS4, MS5, MS6, MS7, MS8 = [(B.KERNEL_MULTISTEP, k) for k in (2, 3, 4, 5, 6, 7, 8)]
-KERNELS = [B.KERNEL_FUSED, B.KERNEL_SPLIT, MS2, MS3, MS4, MS5, MS6, MS7, MS8]
+TL1, TL3, TL8 = [(B.KERNEL_TILE, k) for k in (1, 3, 8)]      # the tiled multi-step sweep of small grids
+KERNELS = [B.KERNEL_FUSED, B.KERNEL_SPLIT, MS2, MS3, MS4, MS5, MS6, MS7, MS8, TL1, TL3, TL8]
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -201,8 +202,9 @@ def test_3d_upsampled_pgm_slices_expanded_on_the_device(oracle, tmp_path):
     assert util.run_and_compare(s, o, 40, 20, "3-D upsampled PGM") == 0
 
 
+@pytest.mark.parametrize("kind", [B.KERNEL_MULTISTEP, B.KERNEL_TILE])
 @pytest.mark.parametrize("seed", range(24))
-def test_2d_multi_step_random_cases(oracle, seed):
+def test_2d_multi_step_random_cases(oracle, seed, kind):
     """Seeded random cases of the multi-step sweep: grid size (strip and band edges included),
     steps per pass, sources (also on the last column and row), tissue maps, rp planes, state and
     the way the steps are cut into calls -- every field bit for bit after every call."""
@@ -212,7 +214,7 @@ def test_2d_multi_step_random_cases(oracle, seed):
     k = int(rng.integers(2, 9))
     nsrc = int(rng.integers(1, 5))
     srcs = [(int(rng.integers(1, nx)), int(rng.integers(1, ny)), 0) for _ in range(nsrc)]
-    s, o = util.pair(oracle, (nx, ny, 1), srcs, CON, kernel=(B.KERNEL_MULTISTEP, k), sigma=0.2, eps_s=9.0, eps_i=3.0,
+    s, o = util.pair(oracle, (nx, ny, 1), srcs, CON, kernel=(kind, k), sigma=0.2, eps_s=9.0, eps_i=3.0,
                      tau_d=2e-11)
     if rng.random() < 0.7:
         codes = rng.integers(0, len(util.RIKEN_LIKE), size=(1, ny, nx), dtype=np.uint8)
@@ -367,9 +369,40 @@ def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path, spp):
         assert np.array_equal(got.view(np.uint32), np.asarray(o.field(fid)[0]).view(np.uint32)), B.FIELD_NAMES[fid]
 
 
+def test_2d_tiled_sweep_tall_tiles_materials_mur_probes(oracle):
+    """1000 x 700: more than 256 tiles of 48 x 48 cells, so the tiled sweep takes its 64-row tiles
+    (smaller grids run the 32-row ones); tissue codes, random rp planes, sources and probes on tile
+    edges (x = 47/48, y = 47/48) and on the faces; fields and probe rows bit for bit."""
+    nx, ny = 1000, 700
+    rng = np.random.default_rng(5)
+    srcs = [(500, 350, 0), (47, 47, 0), (48, 48, 0), (999, 699, 0), (1, 1, 0)]
+    s, o = util.pair(oracle, (nx, ny, 1), srcs, CON, kernel=(B.KERNEL_TILE, 8), sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    assert s.sweep_kernel_name == "fdtd2d_tile"
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=(1, ny, nx), dtype=np.uint8)
+    util.set_materials(s, o, codes)
+    for face in (0, 1, 3, 4):
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    util.randomize(s, o, rng, oracle)
+    probes = [[500, 350, 0], [0, 300, 0], [999, 301, 0], [400, 0, 0], [401, 699, 0], [47, 47, 0], [48, 48, 0], [1, 1, 0]]
+    s.set_probes(probes, capacity=64)
+    series = []
+    peak = util.Peak()
+    for n in (8, 5, 1, 16, 3):
+        for _ in range(n):
+            o.step(1)
+            peak.update(o, util.fields_of(s))
+            series.append([[o.field(f)[0, y, x] for f in (B.HX, B.HY, B.DZ, B.EZ)] for x, y, _ in probes])
+        s.step(n)
+        assert util.compare(s, o, peak, f"tiled sweep after {len(series)} steps") == 0
+    got = s.read_probes(0, len(series))
+    assert np.array_equal(got.view(np.uint32), np.array(series, dtype=np.float32).view(np.uint32))
+
+
 # ------------------------------------------------------------------ results path
 
-@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS5])
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS5, TL1, TL3, TL8])
 def test_probe_series_of_multi_step_passes(oracle, kernel):
     """Probes on grid edges, strip edges (x = 247/248) and band edges (y = 31/32) over passes and
     single steps mixed: every step's row of the ring equals the oracle, bit for bit."""

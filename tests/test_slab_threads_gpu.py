@@ -74,10 +74,12 @@ def check_against_oracle(oracle, dims, srcs, slabs, codes, steps, axis):
 
 
 MS3, MS8 = (B.KERNEL_MULTISTEP, 3), (B.KERNEL_MULTISTEP, 8)
+TL3, TL8 = (B.KERNEL_TILE, 3), (B.KERNEL_TILE, 8)
 
 
 @pytest.mark.parametrize("overlap", [True, False])
 @pytest.mark.parametrize("kernel,world,ny", [(MS8, 2, 150), (MS8, 3, 200), (MS3, 3, 130), (MS8, 3, 40),
+                                             (TL8, 2, 150), (TL8, 3, 200), (TL3, 3, 130), (TL8, 3, 40),
                                              (B.KERNEL_FUSED, 3, 100), (B.KERNEL_SPLIT, 2, 60)])
 def test_2d_slabs_on_threads_equal_oracle(oracle, monkeypatch, kernel, world, ny, overlap):
     """Slab 0 holds the default material only and sits next to slabs with tissue codes: its

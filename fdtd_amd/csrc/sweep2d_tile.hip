@@ -30,6 +30,7 @@
 // reads one pair of E/D arrays and one H generation and writes the other.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "device_math.h"
 
@@ -125,6 +126,10 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
     }
     __syncthreads();
 
+    // `inner` (a compile-time flag): every cell of the tile lies inside the guards of every update,
+    // away from the Mur faces, and the tile holds no source and no probe -- the guards fold away.
+    auto advance = [&](auto inner) {
+    constexpr bool IN = decltype(inner)::value;
     int cb = 0; // buffer holding ez of the level the step starts from
     for (int s = 1; s <= K; ++s) {
         const float jz = a.jz[s - 1];
@@ -141,8 +146,8 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
             const float er[4] = {ez[v].y, ez[v].z, ez[v].w, e_right};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                hx[v][i] = (gy_hx && m_hx[i]) ? hx[v][i] - g.kh_y * (ezu[i] - ez[v][i]) : hx[v][i];
-                hyn[v][i] = (gy_in && m_hy[i]) ? hy[v][i] + g.kh_x * (er[i] - ez[v][i]) : hy[v][i];
+                hx[v][i] = (IN || (gy_hx && m_hx[i])) ? hx[v][i] - g.kh_y * (ezu[i] - ez[v][i]) : hx[v][i];
+                hyn[v][i] = (IN || (gy_in && m_hy[i])) ? hy[v][i] + g.kh_x * (er[i] - ez[v][i]) : hy[v][i];
             }
             hy[v] = hyn[v];
             hxs[r + 1][wx] = hx[v];
@@ -164,17 +169,17 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float val = (dz[v][i] + g.cx * (hy[v][i] - hl[i])) - g.cy * (hx[v][i] - hxb[i]);
-                float d = (gy_in && m_hx[i]) ? val : dzp[v][i];
-                if ((srcbits[v] >> i) & 1u) d = val - jz;
+                float d = (IN || (gy_in && m_hx[i])) ? val : dzp[v][i];
+                if (!IN && ((srcbits[v] >> i) & 1u)) d = val - jz;
                 dn[i] = d;
-                en[i] = (gy_ez && m_ez[i]) ? e_update(m[i], g.dt, ez[v][i], ezp[v][i], d, dz[v][i], dzp[v][i]) : ezp[v][i];
+                en[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m[i], g.dt, ez[v][i], ezp[v][i], d, dz[v][i], dzp[v][i]) : ezp[v][i];
             }
             // fdtd_calculations.cu:369-395
             const bool yok = y >= 1 && y <= g.gny - 2;
-            if (w == 0 && yok)
+            if (!IN && w == 0 && yok)
                 en.x = mur_face(g.dt, a.dx, a.mu0, a.eps0, a.rpx0[(size_t)y * 2], a.rpx0[(size_t)y * 2 + 1], en.y,
                                 ez[v].y, ez[v].x);
-            if (tile_xe) {
+            if (!IN && tile_xe) {
                 const float t_prev = __shfl_up(en.w, 1), s_prev = __shfl_up(ez[v].w, 1);
                 if (w == xe_w && yok) {
                     const float r_here = a.rpxe[(size_t)y * 2 + 1], r_in = a.rpxe[(size_t)y * 2];
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
         __syncthreads();
         // Mur on the y faces, fdtd_calculations.cu:401-427: the face row takes the new and the old
         // level of the row next to it from the two buffers
-        if (tile_y0 || tile_ye) {
+        if (!IN && (tile_y0 || tile_ye)) {
 #pragma unroll
             for (int v = 0; v < V; ++v) {
                 const int r = v * RT + trow, y = y_first + r;
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
         // probe rows of step n+s
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            if (!prb[v]) continue;
+            if (IN || !prb[v]) continue;
             const int slot = s < K ? a.slot[s] : t.slot_last;
             for (int p = 0; p < a.probes.count; ++p) {
                 if (!((prb[v] >> p) & 1u)) continue;
@@ -236,6 +241,23 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
         }
         cb = nb;
     }
+    };
+    bool any_src = false;
+    for (int s = 0; s < a.src.count; ++s) {
+        const int js = a.src.y[s] - g.gy0 - j0, ws = (a.src.x[s] >> 2) - w_first;
+        any_src |= js >= 0 && js < TY && ws >= 0 && ws < WX;
+    }
+    if (a.ring)
+        for (int s = 0; s < a.probes.count; ++s) {
+            const int js = a.probes.y[s] - g.gy0 - j0, ws = (a.probes.x[s] >> 2) - w_first;
+            any_src |= js >= 0 && js < TY && ws >= 0 && ws < WX;
+        }
+    const bool inner_tile = w_first >= 1 && (w_first + WX - 1) * 4 + 3 <= g.nx - 2 && y_first >= 1 &&
+                            y_first + TY - 1 <= g.gny - 2 && !any_src;
+    if (inner_tile)
+        advance(std::true_type{});
+    else
+        advance(std::false_type{});
 
 #pragma unroll
     for (int v = 0; v < V; ++v) {

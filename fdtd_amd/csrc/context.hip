@@ -158,6 +158,7 @@ struct fdtd_ctx {
     float *halo_send[2] = {}, *halo_recv[2] = {};
     bool auto_kernel = false;
     bool interleave3 = false; // 3-D: the three components of a field share one allocation, row by row
+    bool probe_pending = false; // inside fdtd_step(): the newest step's probe row is still to be written
     bool halo_stale = true; // set by everything that changes the state behind the stepper's back
     bool deep() const { return kernel == FDTD_KERNEL_MULTISTEP; }
     size_t deep_count() const { return (size_t)6 * tb_steps * nx + ((size_t)tb_steps * nx + 3) / 4; }
@@ -518,7 +519,9 @@ Mur2D mur2d_args(const fdtd_ctx *c, const Grid2D &g, float *target, const float 
     return m;
 }
 
-int step_once(fdtd_ctx *c)
+// `last`: no further step follows in this fdtd_step() call.  The fused 3-D sweep records the probe
+// row of the step before it, so only the last step of a call needs the probe kernel.
+int step_once(fdtd_ctx *c, bool last)
 {
     int rc = snapshot_guard(c);
     if (rc) return rc;
@@ -625,7 +628,13 @@ int step_once(fdtd_ctx *c)
             f.plane_words = (long long)c->ny * p4;
             // wave-aligned segments: the last lane of a segment is lane 63 of its wave
             f.seg_words = (int)(((f.plane_words + 7) / 8 + 63) / 64 * 64);
-            f.seg_blocks = (f.seg_words + 255) / 256;
+            // 256 threads per block, fewer where the last block of a segment would be mostly idle
+            // (100^3: segments of 384 words)
+            f.block = f.seg_words % 256 == 0 || f.seg_words >= 4096 ? 256 : f.seg_words % 128 == 0 ? 128 : 64;
+            f.seg_blocks = (f.seg_words + f.block - 1) / f.block;
+            f.ring = nullptr;
+            f.probe_slot = 0;
+            f.probes = c->probes;
             for (int s = 0; s < a.src.count; ++s) {
                 const int kz = a.src.z[s] - c->s0;
                 const bool here = kz >= 0 && kz < c->sn;
@@ -644,6 +653,11 @@ int step_once(fdtd_ctx *c)
             }
             f.k_begin = lo;
             f.k_end = hi;
+            if (c->probe_pending) {
+                f.ring = c->probe_ring;
+                f.probe_slot = (int)((c->step - 1) % c->probe_cap);
+                c->probe_pending = false;
+            }
             if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
             launch_sweep3d(f, c->stream);
             c->hgen ^= 1;
@@ -668,7 +682,12 @@ int step_once(fdtd_ctx *c)
     } else if ((rc = exchange_halos(c, c->stream, false))) {
         return rc;
     }
-    record_probes(c, 0);
+    if (!last && !c->is2d() && c->kernel == FDTD_KERNEL_FUSED && c->probes.count > 0 && c->probe_ring) {
+        c->probe_pending = true; // the next step's sweep writes the row
+        record_probes(c, 0, false);
+    } else {
+        record_probes(c, 0);
+    }
     return 0;
 }
 
@@ -1386,7 +1405,7 @@ int fdtd_step(fdtd_ctx *c, int nsteps)
     for (int i = 0; i < nsteps;) {
         // full passes, then one shorter pass for the remainder (a single step: the one-step sweep)
         const int k = std::min(nsteps - i, spp);
-        int rc = (k >= 2 || c->tile) ? pass_once(c, k) : step_once(c);
+        int rc = (k >= 2 || c->tile) ? pass_once(c, k) : step_once(c, i + k >= nsteps);
         if (rc) return rc;
         i += k;
     }

@@ -195,9 +195,15 @@ struct Fused3D {
     int k_begin, k_end;                    // local planes this launch covers
     long long plane_words;                 // 16-byte words of one plane: ny * pitch / 4
     int seg_words;                         // words of one XCD's segment of a plane (plane_words / 8, rounded up)
-    int seg_blocks;                        // 256-thread blocks per segment
+    int seg_blocks;                        // blocks per segment
+    int block;                             // threads per block: 256, or 64 / 128 where 256 would leave waves idle
     long long src_word[FDTD_MAX_SOURCES];  // word holding the source cell, -1 if another slab holds it
     int src_comp[FDTD_MAX_SOURCES];        // which of the word's four cells
+    // The probe row of the step BEFORE this one, read from the arrays this sweep only reads (the
+    // state that step left) by one more workgroup at the end of the grid: a launch less per step.
+    float *ring;                           // nullptr: nothing to record
+    int probe_slot;
+    ProbeList probes;
 };
 
 // Deep halo exchange of the multi-step mode: `depth` rows of every live array (H, both E and D

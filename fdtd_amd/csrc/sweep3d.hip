@@ -56,13 +56,31 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
 {
     const Grid3D &g = a.g;
     const int lane = threadIdx.x & 63;
+    if (a.ring && blockIdx.x == gridDim.x - 1) {
+        // the extra workgroup: the probe row of the previous step, fdtd3d_probe's layout
+        const int i = threadIdx.x;
+        if (i < a.probes.count) {
+            const int kp = a.probes.z[i] - g.gz0;
+            float *dst = a.ring + ((size_t)a.probe_slot * FDTD_MAX_PROBES + i) * 9;
+            const bool in = kp >= 0 && kp < g.nzl && a.probes.x[i] >= 0 && a.probes.x[i] < g.nx && a.probes.y[i] >= 0 &&
+                            a.probes.y[i] < g.ny;
+            const size_t po = in ? ((size_t)(kp + 1) * g.ny + a.probes.y[i]) * g.pitch + a.probes.x[i] : 0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dst[c] = in ? a.h_r[c][po] : 0.f;
+                dst[3 + c] = in ? a.d_n[c][po] : 0.f;
+                dst[6 + c] = in ? a.e_n[c][po] : 0.f;
+            }
+        }
+        return;
+    }
     // Block ids are dealt to the 8 XCDs in turn.  XCD i (block id mod 8) owns segment i --
     // one eighth of the words -- of EVERY plane and walks the planes in z order, so the
     // lines of plane z-1 and z+1 it needs are the ones it pulled into its own L2 a plane ago.
     const int p4 = g.rowlen >> 2;
     const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
     const int k = a.k_begin + (int)(seq / (unsigned)a.seg_blocks);
-    const unsigned in_seg = (seq % (unsigned)a.seg_blocks) * 256u + threadIdx.x;
+    const unsigned in_seg = (seq % (unsigned)a.seg_blocks) * blockDim.x + threadIdx.x;
     const unsigned in_plane = xcd * (unsigned)a.seg_words + in_seg;      // word within the plane
     const int y = (int)(in_plane / (unsigned)p4);
     const int x4 = (int)(in_plane % (unsigned)p4) * 4;
@@ -236,14 +254,15 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
 void launch_sweep3d(const Fused3D &a, void *stream)
 {
     if (a.k_end <= a.k_begin) return;
-    const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)(a.k_end - a.k_begin));
+    const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)(a.k_end - a.k_begin) + (a.ring ? 1u : 0u));
+    const dim3 block((unsigned)a.block);
     static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 3;
 #define GO(W)                                                                                     \
     do {                                                                                          \
         if (a.ntab == 1)                                                                          \
-            hipLaunchKernelGGL((fdtd3d_sweep<true, W>), grid, dim3(256), 0, (hipStream_t)stream, a);  \
+            hipLaunchKernelGGL((fdtd3d_sweep<true, W>), grid, block, 0, (hipStream_t)stream, a);  \
         else                                                                                      \
-            hipLaunchKernelGGL((fdtd3d_sweep<false, W>), grid, dim3(256), 0, (hipStream_t)stream, a); \
+            hipLaunchKernelGGL((fdtd3d_sweep<false, W>), grid, block, 0, (hipStream_t)stream, a); \
     } while (0)
     if (waves == 2)
         GO(2);

@@ -58,7 +58,10 @@ struct StageOut {
 
 // Waves per workgroup: four, except for the table variant at K = 8, whose 20 KB of parked rows per
 // wave plus the 4 KB table allow three (two workgroups per CU either way).
-template <int K, bool ONE> constexpr int tb_waves() { return (!ONE && K >= 8) ? 3 : 4; }
+#ifndef FDTD_TB8_TABLE_WAVES
+#define FDTD_TB8_TABLE_WAVES 3
+#endif
+template <int K, bool ONE> constexpr int tb_waves() { return (!ONE && K >= 8) ? FDTD_TB8_TABLE_WAVES : 4; }
 
 // At least two waves per SIMD (the register allocator otherwise settles for one at some K).
 // PLAIN: loads without the nontemporal hint (the default).
@@ -66,7 +69,7 @@ template <int K, bool ONE> constexpr int tb_waves() { return (!ONE && K >= 8) ? 
 // which the 16-byte rows make every cell rebuild from dt and tau (7 fp64 instructions per cell
 // and stage); at most kWideTableRows material codes.
 template <int K, bool ONE, bool PLAIN, bool WIDE>
-__global__ __launch_bounds__((tb_waves<K, ONE>() * 64), 2) void fdtd2d_sweep_tb(const SweepTB a)
+__global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 ? 1 : 2)) void fdtd2d_sweep_tb(const SweepTB a)
 {
     constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords, WPB = tb_waves<K, ONE>();
     // Grids with several materials: the coefficient table sits in LDS, where a lookup per cell and

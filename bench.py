@@ -71,7 +71,7 @@ def measured_traffic(workload, kernel, spp):
 def issue_bound(solver, k, kernel_ms):
     """Vector-issue estimate of one pass of the multi-step sweep: vector instructions of a row
     iteration (counted in the gfx950 assembly by tools/isa_count.py: fp32/integer 2 cycles, fp64 4
-    cycles per wave64 instruction on a SIMD-32) x row iterations of the launch / (1024 SIMDs x 2.4 GHz)."""
+    cycles per wave64 instruction) x row iterations of the launch / (1024 SIMDs x 2.4 GHz)."""
     try:
         with open(os.path.join(ROOT, "profiles", "isa_counts.json")) as f:
             c = json.load(f)[f"K{k}_one_plain"]["inner_march_per_row_iteration"]
@@ -389,7 +389,7 @@ def main():
                 "bytes_per_cell_update": BYTES_PER_CELL_2D, "GB/s": eq, "ratio_to_peak": eq / HBM_PEAK_GBS,
                 "note": f"{full_k} steps per launch: 41 B x cell-updates / time; exceeds the peak because a pass "
                         "moves 49 B per cell whatever the number of steps"}
-            issue = issue_bound(solver, full_k, sweep_avg_ms)
+            issue = issue_bound(solver, full_k, sweep_avg_ms) if kernel_name == "fdtd2d_sweep_tb" else None
             if issue:
                 out["roofline"]["issue_bound"] = issue
         if world == 1 and not is3d and not args.no_one_step_leg and not args.no_profile and not args.tissue \

@@ -490,6 +490,37 @@ def test_2d_full_size_16384_window_and_causality(oracle):
         del full
 
 
+@pytest.mark.timeout(600)
+def test_2d_tiled_sweep_4096_whole_field_and_auto_choice(oracle):
+    """4096 x 4096: the largest square grid FDTD_KERNEL_AUTO gives to the tiled multi-step sweep
+    (7 310 tiles, guard-free and guarded ones).  Sources near a corner so that the wave meets two
+    Mur faces; 100 steps (12 launches of 8 + one of 4) against the oracle on the whole grid, bit for
+    bit, and the probe series of every step."""
+    n, steps = 4096, 100
+    src = [(60, 70, 0), (2048, 2048, 0)]
+    s = fdtd_amd.Solver(fdtd_amd.make_params(n, n, 1, src), ecoef=CON)
+    assert s.sweep_kernel_name == "fdtd2d_tile" and s.steps_per_pass == 8
+    probes = [[60, 70, 0], [0, 70, 0], [61, 0, 0], [2048, 2049, 0], [4095, 4095, 0]]
+    s.set_probes(probes, capacity=steps)
+    o = oracle.Oracle(oracle.make_params(n, n, 1, src), ecoef=CON)
+    s.step(steps)
+    series = []
+    for _ in range(steps):
+        o.step(1, threads=8)
+        series.append([[o.field(f)[0, y, x] for f in (B.HX, B.HY, B.DZ, B.EZ)] for x, y, _ in probes])
+    for fid in (B.HX, B.HY, B.DZ, B.EZ):
+        got, want = s.field(fid), np.asarray(o.field(fid))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), B.FIELD_NAMES[fid]
+        assert np.abs(got).max() > 0
+    want = np.array(series, dtype=np.float32)
+    assert np.abs(want[:, 1:3, 3]).max() > 0          # the wave reached the face probes
+    assert np.array_equal(s.read_probes(0, steps).view(np.uint32), want.view(np.uint32))
+    s.close()
+    big = fdtd_amd.Solver(fdtd_amd.make_params(8192, 4096, 1, [(100, 100, 0)]), ecoef=CON)
+    assert big.sweep_kernel_name == "fdtd2d_sweep_tb"      # 33 M cells: the row-marching sweep
+    big.close()
+
+
 @pytest.mark.timeout(900)
 def test_2d_largest_grid_65536_window_and_causality(oracle):
     """65536 x 65536 (4.3 G cells, 210 GB resident: byte offsets need 38 bits), source off

@@ -749,6 +749,49 @@ void tb_rows_of(const fdtd_ctx *c, SweepTB &a, int y_begin, int y_end)
 
 int finish_pass(fdtd_ctx *c, const SweepTB &a, int K, const Split &sp, int lo, int hi, bool tail);
 
+// The waves of a launch (bands as tb_rows_of laid them out, map 0) that hold a source or a probe of
+// this slab, for SweepTB::first.
+void tb_first_waves(const fdtd_ctx *c, SweepTB &a, int K)
+{
+    a.nfirst = 0;
+    a.faces_first = 0;
+    if (a.map != 0) return;
+    std::vector<std::pair<int, int>> bands; // rows [y0, y1) of every band, in launch order
+    for (int b = 0; b < a.big_bands; ++b) bands.push_back({a.y_begin + b * a.rows, std::min(a.y_begin + (b + 1) * a.rows, a.y_end)});
+    for (int y = a.tail_begin; y < a.y_end; y += a.tail_rows) bands.push_back({y, std::min(y + a.tail_rows, a.y_end)});
+    static const bool faces = !std::getenv("FDTD_TB_FACES_FIRST") || std::atoi(std::getenv("FDTD_TB_FACES_FIRST"));
+    a.faces_first = (faces && a.strips > 2) ? (int)bands.size() : 0;
+    std::vector<int> ids;
+    auto add = [&](int x, int j, bool window) {
+        // a source counts for every wave whose window (halo words and primed rows included) holds it,
+        // a probe for the wave that owns its cell
+        const int w = x >> 2;
+        for (size_t b = 0; b < bands.size(); ++b) {
+            const int lo = window ? bands[b].first - K : bands[b].first, hi = window ? bands[b].second + K - 2 : bands[b].second - 1;
+            if (j < lo || j > hi) continue;
+            for (int s = 0; s < a.strips; ++s) {
+                const int w0 = s * kTbOwnWords - (window ? kTbHaloWords : 0), w1 = s * kTbOwnWords + kTbOwnWords + (window ? kTbHaloWords : 0);
+                if (w >= w0 && w < w1) {
+                    const int nb = a.faces_first;
+                    // place of band b in the launch: the last band comes second
+                    const int d = (!nb || nb < 3) ? (int)b : b == 0 ? 0 : (int)b == nb - 1 ? 1 : (int)b + 1;
+                    ids.push_back(!nb ? (int)b * a.strips + s
+                                      : s == 0 ? 2 * d : s == a.strips - 1 ? 2 * d + 1 : 2 * nb + d * (a.strips - 2) + s - 1);
+                }
+            }
+        }
+    };
+    for (int s = 0; s < a.src.count; ++s) add(a.src.x[s], a.src.y[s] - c->s0, true);
+    if (a.ring)
+        for (int s = 0; s < a.probes.count; ++s)
+            if (a.probes.x[s] >= 0 && a.probes.x[s] < c->nx) add(a.probes.x[s], a.probes.y[s] - c->s0, false);
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    if (ids.size() > (size_t)kTbFirstWaves) ids.resize(kTbFirstWaves);
+    a.nfirst = (int)ids.size();
+    for (size_t i = 0; i < ids.size(); ++i) a.first[i] = ids[i];
+}
+
 // MULTISTEP: K <= tb_steps time steps in one pass (sweep2d_tb.hip), then Mur on the newest level;
 // the tiled sweep (sweep2d_tile.hip) does all of it in one launch.
 int pass_once(fdtd_ctx *c, int K)
@@ -794,6 +837,7 @@ int pass_once(fdtd_ctx *c, int K)
     a.strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
     a.map = c->tb_map;
     a.strips_per_xcd = (a.strips + 7) / 8;
+    a.nfirst = a.faces_first = 0;
 
     // The rows within `edge` of a neighbour slab go first, on xstream, and the deep-halo exchange
     // follows them there while the main stream sweeps the interior.
@@ -843,6 +887,8 @@ int pass_once(fdtd_ctx *c, int K)
         }
     }
     tb_rows_of(c, a, lo, hi);
+    static const bool reorder = !std::getenv("FDTD_TB_FIRST") || std::atoi(std::getenv("FDTD_TB_FIRST"));
+    if (reorder) tb_first_waves(c, a, K);
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (launch_sweep2d_tb(a, K, c->stream)) {
         set_error("no multi-step kernel for this number of steps per pass");

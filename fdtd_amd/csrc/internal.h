@@ -90,6 +90,7 @@ constexpr int kFastStepsPerPassTable = 7; // grids with several materials: the t
 constexpr int kDefaultStepsPerPass = 8; // 16384^2 vacuum: 4: 358, 5: 430, 6: 498, 7: 562, 8: 612 Gcell-updates/s
 constexpr int kTbOwnWords = 60; // 16-byte words of a row a wave owns
 constexpr int kTbHaloWords = 2; // words it holds on either side of them
+constexpr int kTbFirstWaves = 64; // waves a launch can move to its front
 struct SweepTB {
     Grid2D g;
     const float *hx_r, *hy_r;   // H, read generation (step n - 1/2)
@@ -116,6 +117,15 @@ struct SweepTB {
     // to another launch of the same pass).
     int y_begin, y_end, tail_begin;
     int big_bands, tail_rows;
+    // Waves that hold a source or a probe run the guarded copy of the loop for their whole band and
+    // take about twice as long: started in the middle of a launch they finish after everybody else.
+    // They go first: position i < nfirst of the launch does the work of wave first[i] (ascending), the
+    // positions after them the other waves in their order (map 0 only).
+    int nfirst;
+    int first[kTbFirstWaves];
+    // 0, or the number of bands of the launch: waves are then numbered with the two strips on the x
+    // faces of every band first (2 * band + side), the inner strips after them band by band.
+    int faces_first;
     int strips;                           // waves across a row (kTbOwnWords owned words each)
     int map;                              // 0: waves numbered band by band; 1: each XCD walks its own panel of strips
     int strips_per_xcd;                   // map 1: ceil(strips / 8)

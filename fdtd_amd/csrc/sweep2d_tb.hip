@@ -90,9 +90,34 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
     const int lane = threadIdx.x & 63;
     int strip, band;
     if (a.map == 0) {
-        const long wv = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
-        strip = (int)(wv % a.strips);
-        band = (int)(wv / a.strips);
+        long wv = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+        if (a.nfirst > 0) {
+            // the waves listed in first[] (ascending) go first, the others follow in their order
+            if (wv < a.nfirst) {
+                wv = a.first[wv];
+            } else {
+                wv -= a.nfirst;
+                for (int i = 0; i < a.nfirst; ++i)
+                    if (a.first[i] <= wv) ++wv;
+            }
+        }
+        if (a.faces_first) {
+            // the two strips on the x faces of every band (guarded loop: slow waves) before the others
+            const long nb = a.faces_first; // bands of the launch
+            if (wv < 2 * nb) {
+                strip = (wv & 1) ? a.strips - 1 : 0;
+                band = (int)(wv >> 1);
+            } else {
+                const long q = wv - 2 * nb;
+                strip = 1 + (int)(q % (a.strips - 2));
+                band = (int)(q / (a.strips - 2));
+            }
+            // and the last band (the y face at the upper end: guarded too) right after the first
+            if (nb >= 3) band = band == 1 ? (int)nb - 1 : band > 1 ? band - 1 : 0;
+        } else {
+            strip = (int)(wv % a.strips);
+            band = (int)(wv / a.strips);
+        }
     } else {
         // Block ids are dealt to the 8 XCDs in turn: XCD i (block id mod 8) walks panel i, a run of
         // strips_per_xcd adjacent strips, band after band, so the lines two adjacent strips share are

@@ -1057,17 +1057,15 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         return -3;
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->tb_rows == 0) {
-        // 32 to 64 rows per wave keep the recomputed rows (2K - 1 per wave) cheap; smaller grids trade
-        // that for enough waves to fill the 256 CUs
+        // Rows per wave: tall bands keep the rows a wave re-marches (2K - 1 per band) cheap, short ones give
+        // the launch enough waves to keep 2048 of them in flight until its end.  Measured optimum: about
+        // 4800 waves per launch, at most 176 rows (16384^2: 176 rows 779 Gcell-updates/s, 96 rows 728;
+        // 8480x15680: 96 and 112 rows 612, 64 and 128 rows 590; 12288^2: 128 rows 706, 160 rows 677;
+        // 8192^2: 64 rows 613, 32 rows 520).
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
-        // (measured: 16384^2 96 rows at K = 8 and 64 at K = 6, 8192^2 32, 4096^2 and 3072^2 16):
-        // the tallest of these that still gives 8192 waves
-        const int heights[] = {96, 64, 32, 16, 8, 4};
-        const int first = c->tb_steps >= 7 ? 0 : c->tb_steps >= 5 ? 1 : 2;
-        const int last = (double)c->nx * c->sn >= 6e6 ? 3 : 5;
-        int pick = first;
-        while (pick < last && ((c->sn + heights[pick] - 1) / heights[pick]) * strips < 8192) ++pick;
-        c->tb_rows = heights[pick];
+        const long want = ((long)c->sn * strips / 4800 + 8) / 16 * 16;
+        c->tb_rows = (int)std::min(176L, std::max(16L, want));
+        if ((double)c->nx * c->sn < 6e6) c->tb_rows = (int)std::max(4L, std::min((long)c->tb_rows, (long)c->sn * strips / 2048));
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->sn != c->gn && c->sn < c->tb_steps) {
         set_error("a slab of the multi-step mode must hold at least steps_per_pass rows");

@@ -769,7 +769,9 @@ void tb_first_waves(const fdtd_ctx *c, SweepTB &a, int K)
         for (size_t b = 0; b < bands.size(); ++b) {
             const int lo = window ? bands[b].first - K : bands[b].first, hi = window ? bands[b].second + K - 2 : bands[b].second - 1;
             if (j < lo || j > hi) continue;
-            for (int s = 0; s < a.strips; ++s) {
+            // the strips whose words [w0, w1) hold word w: at most two
+            const int s_lo = std::max(0, (w - kTbOwnWords - kTbHaloWords + 1) / kTbOwnWords - 1);
+            for (int s = s_lo; s < std::min(a.strips, s_lo + 4); ++s) {
                 const int w0 = s * kTbOwnWords - (window ? kTbHaloWords : 0), w1 = s * kTbOwnWords + kTbOwnWords + (window ? kTbHaloWords : 0);
                 if (w >= w0 && w < w1) {
                     const int nb = a.faces_first;

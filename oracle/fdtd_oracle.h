@@ -5,15 +5,24 @@
  * nothing in the shipped library may include, link or call it.  Only tests/,
  * __graft_entry__.smoke() and the cpu_baseline leg of bench.py use it.
  *
- * Pinning status: the reference has no tests, golden vectors or fixtures, and
- * it cannot be built in this image (it needs nvcc and the CUDA runtime; writing
- * stand-ins for them is not allowed).  The only reference-derived numbers
- * available are the known-answer values recorded when the reference was
- * surveyed (derived constants, jz anchors, rp planes, an 11-row probe series of
- * the shipped 100^3 vacuum case); tests/golden/survey_known_answers.json holds
- * them and tests/test_oracle_golden.py checks this file against every one.
- * The Debye-material and Mur-absorber terms have no reference-derived vector:
- * for those, parity is UNPINNED and rests on this restatement alone.
+ * Pinning status.  The reference has no tests, golden vectors or fixtures and
+ * its executable cannot be built here (nvcc and the CUDA runtime are absent).
+ * Two things pin this file:
+ *  - the reference's OWN kernel file, fdtd_calculations.cu, translated by the
+ *    image's hipify-perl (cuda* runtime names -> hip*, nothing else) and built for
+ *    gfx950 with -ffp-contract=off by `make ref` into _ref/libfdtd_ref.so
+ *    (ref_driver.hip launches the five kernels in main's order and rotation):
+ *    tests/test_reference_kernels_gpu.py compares the 3-D update -- H, D,
+ *    sources, Debye E update, all twelve Mur cases, every phase of the buffer
+ *    rotation -- with it on the GPU, every cell of every buffer bit for bit;
+ *  - the known-answer values recorded when the reference was surveyed (derived
+ *    constants, jz anchors, rp planes, an 11-row probe series of the shipped
+ *    100^3 vacuum case): tests/golden/survey_known_answers.json and
+ *    tests/test_oracle_golden.py (CPU only).  They are the only pins of the
+ *    input surface (parameter parse, source waveform, rp formula).
+ * UNPINNED: the 2-D TMz reduction (the reference has no 2-D mode: with nz = 1
+ * none of its guards passes) and the CONSISTENT coefficient variant, which are
+ * defined by this restatement.
  *
  * Every function cites the reference file:line it follows.  Arithmetic follows
  * the reference's C promotions (fp32 fields, fp64 in-flight in the E update)

@@ -56,6 +56,11 @@ struct StageOut {
     f4 ez, hx, hy, dz;
 };
 
+// Which guards a copy of the marching loop folds away at compile time.
+template <bool INX, bool INY> struct LoopMode {
+    static constexpr bool inx = INX, iny = INY;
+};
+
 // Waves per workgroup: four, except for the table variant at K = 8, whose 20 KB of parked rows per
 // wave plus the 4 KB table allow three (two workgroups per CU either way).
 #ifndef FDTD_TB8_TABLE_WAVES
@@ -185,9 +190,11 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
     // row r - 1) -> level s of row r.
     // `inner` (a compile-time flag): the wave and all its rows lie inside the guards of every
     // update, away from the Mur faces, sources and probes -- the guards fold away.
-    auto stage = [&](auto inner, const Level &in, const f4 &hyin, const f4 &ezp, const f4 &dzp, const f4 &ezu,
+    auto stage = [&](auto mode, const Level &in, const f4 &hyin, const f4 &ezp, const f4 &dzp, const f4 &ezu,
                      const f4 &hxb, int r, float jz) -> StageOut {
-        constexpr bool IN = decltype(inner)::value;
+        // INX: every lane holds cells 1 .. nx-2 only; INY: every row any stage touches lies in 2 .. ny-3
+        // and the wave holds no source and no probe.  The guards of a folded direction vanish.
+        constexpr bool INX = decltype(mode)::inx, INY = decltype(mode)::iny;
         const int y = g.gy0 + r;
         const bool gy_hx = y >= 0 && y <= g.gny - 2;
         const bool gy_in = y >= 1 && y <= g.gny - 2;
@@ -213,14 +220,14 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
         const float er[4] = {in.ez.y, in.ez.z, in.ez.w, e_right};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            o.hx[i] = (IN || (gy_hx && m_hx[i])) ? in.hx[i] - g.kh_y * (ezu[i] - in.ez[i]) : in.hx[i];
-            o.hy[i] = (IN || (gy_in && m_hy[i])) ? hyin[i] + g.kh_x * (er[i] - in.ez[i]) : hyin[i];
+            o.hx[i] = ((INY || gy_hx) && (INX || m_hx[i])) ? in.hx[i] - g.kh_y * (ezu[i] - in.ez[i]) : in.hx[i];
+            o.hy[i] = ((INY || gy_in) && (INX || m_hy[i])) ? hyin[i] + g.kh_x * (er[i] - in.ez[i]) : hyin[i];
         }
         const float hy_left = __shfl_up(o.hy.w, 1);
         const float hl[4] = {hy_left, o.hy.x, o.hy.y, o.hy.z};
 
         unsigned srcflag = 0;
-        if (!IN && srcmask) {
+        if (!INY && srcmask) {
             for (int s = 0; s < a.src.count; ++s) {
                 if (!((srcmask >> s) & 1u) || a.src.y[s] - g.gy0 != r) continue;
                 if ((a.src.x[s] >> 2) == w) srcflag |= 1u << (a.src.x[s] & 3);
@@ -229,8 +236,8 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float v = (in.dz[i] + g.cx * (o.hy[i] - hl[i])) - g.cy * (o.hx[i] - hxb[i]);
-            float dn = (IN || (gy_in && m_hx[i])) ? v : dzp[i];
-            if (!IN && ((srcflag >> i) & 1u)) dn = v - jz;
+            float dn = ((INY || gy_in) && (INX || m_hx[i])) ? v : dzp[i];
+            if (!INY && ((srcflag >> i) & 1u)) dn = v - jz;
             o.dz[i] = dn;
         }
 
@@ -238,20 +245,20 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
             if (words_uniform) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update_wide(mu, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                    o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? e_update_wide(mu, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
                                                          : ezp[i];
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const MatCoef mi = tabw[(in.cd >> (8 * i)) & 0xffu];
-                    o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update_wide(mi, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                    o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? e_update_wide(mi, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
                                                          : ezp[i];
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
-                o.ez[i] = (IN || (gy_ez && m_ez[i])) ? e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
                                                      : ezp[i];
         }
         return o;
@@ -310,8 +317,8 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
         unsigned cd;
     };
     auto ld4 = [&](const float *p) -> f4 { return PLAIN ? *(const f4 *)p : ld4_stream(p); };
-    auto load = [&](auto inner, RowIn &r, int j) {
-        const bool ld = decltype(inner)::value || act;
+    auto load = [&](auto mode, RowIn &r, int j) {
+        const bool ld = decltype(mode)::inx || act;
         const long off = (long)(j + 1) * pitch + x4;
         r.hx = ld ? ld4(a.hx_r + off) : zero;
         r.hy = ld ? ld4(a.hy_r + off) : zero;
@@ -323,8 +330,8 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
         r.cd = (!ONE && ld) ? *(const unsigned *)(a.code + (long)(j + 1) * g.cpitch + x4) : 0u;
     };
 
-    auto march = [&](auto inner) {
-    constexpr bool IN = decltype(inner)::value;
+    auto march = [&](auto mode) {
+    constexpr bool INX = decltype(mode)::inx, INY = decltype(mode)::iny;
     // c[s]: level s-1 of the row stage s works on next (c[1] comes from memory).  While stage s
     // works on row r, c[s + 1] still holds level s of row r - 1: its hx is the hx below that the
     // D update of stage s needs; the last stage keeps that row's hx in hx_top.
@@ -337,8 +344,8 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
         c[s].cd = 0;
     }
     RowIn cur;
-    load(inner, cur, jlo);
-    f4 ezc = (IN || act) ? ld4(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
+    load(mode, cur, jlo);
+    f4 ezc = (INX || act) ? ld4(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
 
     for (int j = jlo; j <= jhi; ++j) {
         RowIn nxt;
@@ -373,14 +380,14 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
                     park(s - 2, 2) = pend_h;
                 }
             }
-            StageOut o = stage(inner, c[s], hyin, ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r,
+            StageOut o = stage(mode, c[s], hyin, ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r,
                                a.jz[s - 1]);
             // the next row's loads go out once stage 1 has consumed this row's registers
-            if (s == 1 && j < jhi) load(inner, nxt, j + 1);
+            if (s == 1 && j < jhi) load(mode, nxt, j + 1);
             if (s < K) {
                 const int y = g.gy0 + r;
-                if (!IN) mur_x(o.ez, c[s].ez, r);
-                if (!IN && (y == g.gny - 1 || y == 1)) {
+                if (!INX) mur_x(o.ez, c[s].ez, r);
+                if (!INY && (y == g.gny - 1 || y == 1)) {
                     // ez of level s-1 of row r - 1 is parked in the slot of stage s + 1
                     const f4 below = park(s - 1, 0);
                     if (y == 1)
@@ -389,7 +396,7 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
                         mur_y(o.ez, c[s + 1].ez, below, c[s].ez, a.rpye, true);
                 }
                 // c[s + 1] now holds the final level s of row r - 1
-                if (!IN && prbmask && own && r - 1 >= y0 && r - 1 < y1)
+                if (!INY && prbmask && own && r - 1 >= y0 && r - 1 < y1)
                     record(c[s + 1], (HY_LAST_IN_REGS && s + 1 == K) ? hy_last : park(s - 1, 2), r - 1, a.slot[s]);
                 keep[s + 1].ez = o.ez;
                 keep[s + 1].hx = o.hx;
@@ -420,14 +427,16 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
     }
     };
 
-    // Inner wave: every lane holds cells 1 .. nx-2 only, every row any stage touches (down to
-    // jlo - (K - 1), whose values are never used) lies in 2 .. ny-3, no source, no probe.
-    const bool inner_wave = w_first >= 1 && (w_first + 63) * 4 + 3 <= g.nx - 2 && g.gy0 + jlo - (K - 1) >= 2 &&
-                            g.gy0 + jhi + 1 <= g.gny - 3 && srcmask == 0 && prbmask == 0;
-    if (inner_wave)
-        march(std::true_type{});
+    // Three copies of the loop: guards folded in both directions (most waves), in y only (the strips on
+    // the x faces, in bands away from the y faces: otherwise the slowest waves of a launch), none folded.
+    const bool inner_x = w_first >= 1 && (w_first + 63) * 4 + 3 <= g.nx - 2;
+    const bool inner_y = g.gy0 + jlo - (K - 1) >= 2 && g.gy0 + jhi + 1 <= g.gny - 3 && srcmask == 0 && prbmask == 0;
+    if (inner_x && inner_y)
+        march(LoopMode<true, true>{});
+    else if (inner_y)
+        march(LoopMode<false, true>{});
     else
-        march(std::false_type{});
+        march(LoopMode<false, false>{});
 }
 
 template <int K> int launch_k(const SweepTB &a, hipStream_t stream)

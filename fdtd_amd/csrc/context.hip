@@ -1015,13 +1015,14 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     c->kernel = opt->kernel;
     c->auto_kernel = c->kernel == FDTD_KERNEL_AUTO;
     if (c->kernel == FDTD_KERNEL_AUTO) {
-        // 2-D: the row-marching multi-step sweep from 24 M cells up; below, a pass of it is bound by
+        // 2-D: the row-marching multi-step sweep from 7 M cells up; below, a pass of it is bound by
         // the latency of its march, not by bandwidth, and the tiled multi-step sweep is faster
-        // (4096^2: 340 against 297 Gcell-updates/s, 3072^2: 292 against 227; 8192^2: 311 against 468).
+        // (2048^2: 302 against 205 Gcell-updates/s, 1024^2: 165 against 81; 3072^2: 292 against 318,
+        // 4096^2: 340 against 347, 8192^2: 311 against 592).
         // Decided from the extents of the WHOLE grid, so that every slab of it takes the same kernel.
         // Smaller 2-D grids are bound by launch and memory latency: the tiled sweep advances them
         // several steps per launch out of registers and LDS.
-        c->kernel = !c->is2d() ? FDTD_KERNEL_FUSED : (double)p->nx * (double)p->ny >= 24e6 ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_TILE;
+        c->kernel = !c->is2d() ? FDTD_KERNEL_FUSED : (double)p->nx * (double)p->ny >= 7e6 ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_TILE;
     }
     if (c->kernel == FDTD_KERNEL_TILE) {
         // the storage, the schedule and the halo protocol of the multi-step mode, another sweep kernel

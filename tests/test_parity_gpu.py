@@ -492,13 +492,12 @@ def test_2d_full_size_16384_window_and_causality(oracle):
 
 @pytest.mark.timeout(600)
 def test_2d_tiled_sweep_4096_whole_field_and_auto_choice(oracle):
-    """4096 x 4096: the largest square grid FDTD_KERNEL_AUTO gives to the tiled multi-step sweep
-    (7 310 tiles, guard-free and guarded ones).  Sources near a corner so that the wave meets two
+    """4096 x 4096 with the tiled multi-step sweep (7 396 tiles, guard-free and guarded ones).  Sources near a corner so that the wave meets two
     Mur faces; 100 steps (12 launches of 8 + one of 4) against the oracle on the whole grid, bit for
     bit, and the probe series of every step."""
     n, steps = 4096, 100
     src = [(60, 70, 0), (2048, 2048, 0)]
-    s = fdtd_amd.Solver(fdtd_amd.make_params(n, n, 1, src), ecoef=CON)
+    s = fdtd_amd.Solver(fdtd_amd.make_params(n, n, 1, src), ecoef=CON, kernel=B.KERNEL_TILE)
     assert s.sweep_kernel_name == "fdtd2d_tile" and s.steps_per_pass == 8
     probes = [[60, 70, 0], [0, 70, 0], [61, 0, 0], [2048, 2049, 0], [4095, 4095, 0]]
     s.set_probes(probes, capacity=steps)
@@ -516,9 +515,11 @@ def test_2d_tiled_sweep_4096_whole_field_and_auto_choice(oracle):
     assert np.abs(want[:, 1:3, 3]).max() > 0          # the wave reached the face probes
     assert np.array_equal(s.read_probes(0, steps).view(np.uint32), want.view(np.uint32))
     s.close()
-    big = fdtd_amd.Solver(fdtd_amd.make_params(8192, 4096, 1, [(100, 100, 0)]), ecoef=CON)
-    assert big.sweep_kernel_name == "fdtd2d_sweep_tb"      # 33 M cells: the row-marching sweep
-    big.close()
+    # FDTD_KERNEL_AUTO: the tiled sweep below 7 M cells, the row-marching one from there on
+    for dims, name in (((2048, 2048), "fdtd2d_tile"), ((3072, 3072), "fdtd2d_sweep_tb")):
+        auto = fdtd_amd.Solver(fdtd_amd.make_params(*dims, 1, [(100, 100, 0)]), ecoef=CON)
+        assert auto.sweep_kernel_name == name, dims
+        auto.close()
 
 
 @pytest.mark.timeout(900)

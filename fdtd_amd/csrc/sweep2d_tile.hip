@@ -50,6 +50,9 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
     __shared__ f4 ezs[2][TY + 2][WX];
     __shared__ f4 hxs[TY + 2][WX];
     __shared__ MatEntry tab[ONE ? 1 : FDTD_MAX_CODES];
+    // the field-independent factors of the Mur update (two square roots and a division per face cell)
+    // are taken once per launch: [side][tile row] for the x faces, [side][column of the tile] for the y faces
+    __shared__ f4 mur_xc[2][TY], mur_yc[2][WX * 4];
     const int tid = threadIdx.x;
     if (!ONE)
         for (int i = tid; i < FDTD_MAX_CODES; i += NT) tab[i] = a.table[i];
@@ -110,6 +113,21 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
                 if (a.probes.y[s] - g.gy0 == j && a.probes.x[s] >= 0 && a.probes.x[s] < g.nx && (a.probes.x[s] >> 2) == w)
                     prb[v] |= 1u << s;
         ezs[0][r + 1][wx] = ez[v];
+        const int y = g.gy0 + j;
+        if (y >= 1 && y <= g.gny - 2) {
+            if (w == 0) mur_xc[0][r] = mur_coefs(g.dt, a.dx, a.mu0, a.eps0, a.rpx0[(size_t)y * 2], a.rpx0[(size_t)y * 2 + 1]);
+            if (w == xe_w) mur_xc[1][r] = mur_coefs(g.dt, a.dx, a.mu0, a.eps0, a.rpxe[(size_t)y * 2 + 1], a.rpxe[(size_t)y * 2]);
+        }
+        if (y == 0 || y == g.gny - 1) {
+            const bool high = y != 0;
+            const float *rp = high ? a.rpye : a.rpy0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (m_hx[i]) {
+                    const int x = x4 + i;
+                    mur_yc[high][wx * 4 + i] = mur_coefs(g.dt, a.dy, a.mu0, a.eps0, high ? rp[g.nx + x] : rp[x], high ? rp[x] : rp[g.nx + x]);
+                }
+        }
     }
     if (trow == 0) {
         ezs[0][0][wx] = ezs[1][0][wx] = hxs[0][wx] = zero;
@@ -176,18 +194,16 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
             }
             // fdtd_calculations.cu:369-395
             const bool yok = y >= 1 && y <= g.gny - 2;
-            if (!IN && w == 0 && yok)
-                en.x = mur_face(g.dt, a.dx, a.mu0, a.eps0, a.rpx0[(size_t)y * 2], a.rpx0[(size_t)y * 2 + 1], en.y,
-                                ez[v].y, ez[v].x);
+            if (!IN && w == 0 && yok) en.x = mur_apply(mur_xc[0][r], en.y, ez[v].y, ez[v].x);
             if (!IN && tile_xe) {
                 const float t_prev = __shfl_up(en.w, 1), s_prev = __shfl_up(ez[v].w, 1);
                 if (w == xe_w && yok) {
-                    const float r_here = a.rpxe[(size_t)y * 2 + 1], r_in = a.rpxe[(size_t)y * 2];
+                    const f4 c = mur_xc[1][r];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (i == xe_c) {
                             const float t_in = i ? en[i ? i - 1 : 0] : t_prev, s_in = i ? ez[v][i ? i - 1 : 0] : s_prev;
-                            en[i] = mur_face(g.dt, a.dx, a.mu0, a.eps0, r_here, r_in, t_in, s_in, ez[v][i]);
+                            en[i] = mur_apply(c, t_in, s_in, ez[v][i]);
                         }
                 }
             }
@@ -208,13 +224,10 @@ __global__ __launch_bounds__(WX *RT) void fdtd2d_tile(const SweepTile t)
                 if (!(low || high) || g.gny < 2) continue;
                 const int rin = low ? r + 1 : r - 1;
                 const f4 et_in = ezs[nb][rin + 1][wx], es_in = ezs[cb][rin + 1][wx];
-                const float *rp = low ? a.rpy0 : a.rpye;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if (!m_hx[i]) continue;
-                    const int x = x4 + i;
-                    const float r_face = high ? rp[g.nx + x] : rp[x], r_next = high ? rp[x] : rp[g.nx + x];
-                    ez[v][i] = mur_face(g.dt, a.dy, a.mu0, a.eps0, r_face, r_next, et_in[i], es_in[i], ezp[v][i]);
+                    ez[v][i] = mur_apply(mur_yc[high][wx * 4 + i], et_in[i], es_in[i], ezp[v][i]);
                 }
                 ezs[nb][r + 1][wx] = ez[v];
             }

@@ -1017,8 +1017,8 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     if (c->kernel == FDTD_KERNEL_AUTO) {
         // 2-D: the row-marching multi-step sweep from 7 M cells up; below, a pass of it is bound by
         // the latency of its march, not by bandwidth, and the tiled multi-step sweep is faster
-        // (2048^2: 302 against 205 Gcell-updates/s, 1024^2: 165 against 81; 3072^2: 292 against 318,
-        // 4096^2: 340 against 347, 8192^2: 311 against 592).
+        // (2048^2: 311 against 205 Gcell-updates/s, 1024^2: 211 against 81; 3072^2: 315 against 319,
+        // 4096^2: 349 against 347, 8192^2: 378 against 645).
         // Decided from the extents of the WHOLE grid, so that every slab of it takes the same kernel.
         // Smaller 2-D grids are bound by launch and memory latency: the tiled sweep advances them
         // several steps per launch out of registers and LDS.

@@ -111,7 +111,9 @@ struct fdtd_ctx {
     int64_t step = 0;
 
     MaterialRow mats[FDTD_MAX_CODES];
-    int ntab = 1;      // 1 + the highest device code on the owned rows (1: every owned cell holds the default material)
+    int ntab = 1;      // 1 + the highest device code on the owned rows; 1 when every owned cell holds ONE material
+                       // (the kernels then take its coefficients from their arguments, table0, and read no code)
+    int one_code = 0;  // the device code behind table0: 0 (the defaults), or the single code of a whole grid
     int ntab_halo = 1; // the same for the material codes received into the deep halo rows
     int halo_top[2] = {0, 0};
     bool spp_fixed = false; // steps per pass do not depend on the materials (slabs, or set by the caller)
@@ -263,7 +265,7 @@ int upload_table(fdtd_ctx *c)
         t[device_code((uint8_t)i)] = {k.a, k.c, k.d, c->mats[i].tau_d};
         w[device_code((uint8_t)i)] = k;
     }
-    c->table0 = t[0];
+    c->table0 = t[c->one_code];
     HIPCHK(hipMemcpyAsync(c->table, t.data(), t.size() * sizeof(MatEntry), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->table_wide, w.data(), w.size() * sizeof(MatCoef), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -312,6 +314,18 @@ int field_view(fdtd_ctx *c, int field, int level, FieldView *v)
     return 0;
 }
 
+// After the code array changed: `top` = the highest device code on the owned cells, `single` = the
+// code every owned cell holds, or -1.  A WHOLE grid of one material, whichever it is, runs the
+// single-material kernels with that material's row as their argument; a slab only when the material
+// is the default one (its halo rows hold the neighbours' codes, of which only the highest is known).
+int set_code_range(fdtd_ctx *c, int top, int single)
+{
+    const bool whole = c->sn == c->gn;
+    c->one_code = (single > 0 && whole) ? single : 0;
+    c->ntab = (single == 0 || c->one_code > 0) ? 1 : top + 1;
+    return upload_table(c);
+}
+
 int upload_codes(fdtd_ctx *c)
 {
     // owned rows only; halo rows keep the default code (their E is never updated here)
@@ -323,11 +337,12 @@ int upload_codes(fdtd_ctx *c)
         dev[i] = device_code(c->codes_host[i]);
         top = std::max(top, (int)dev[i]);
     }
-    c->ntab = top + 1;
     HIPCHK(hipMemcpy2DAsync(dst, c->cpitch, dev.data(), c->nx, c->nx, rows, hipMemcpyHostToDevice,
                             c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    return 0;
+    bool same = !dev.empty();
+    for (size_t i = 1; i < dev.size() && same; ++i) same = dev[i] == dev[0];
+    return set_code_range(c, top, same ? (int)dev[0] : -1);
 }
 
 int use_device(const fdtd_ctx *c)
@@ -1315,7 +1330,12 @@ int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir
                     dev[i] = device_code(c->codes_base[i]);
                     if (r >= r0 && r <= r1) top = std::max(top, (int)dev[i]);
                 }
-        c->ntab = top + 1;
+        bool same = true;
+        if (!c->is2d() || (r0 == 0 && r1 == by - 1)) {
+            for (size_t i = 1; i < dev.size() && same; ++i) same = dev[i] == dev[0];
+        } else {
+            same = false; // a slab of an upsampled map: only the highest code of its rows is looked at
+        }
         uint8_t *dbase = nullptr;
         HIPCHK(hipMalloc((void **)&dbase, dev.size()));
         hipError_t e = hipMemcpyAsync(dbase, dev.data(), dev.size(), hipMemcpyHostToDevice, c->stream);
@@ -1341,7 +1361,7 @@ int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir
             set_error(std::string("fdtd_load_materials: ") + hipGetErrorString(e));
             return -10;
         }
-        if ((rc = upload_table(c))) return rc;
+        if ((rc = set_code_range(c, top, same && !dev.empty() ? (int)dev[0] : -1))) return rc;
         c->halo_stale = true;
         return 0;
     }

@@ -400,6 +400,27 @@ def test_2d_tiled_sweep_tall_tiles_materials_mur_probes(oracle):
     assert np.array_equal(got.view(np.uint32), np.array(series, dtype=np.float32).view(np.uint32))
 
 
+@pytest.mark.parametrize("dims,kernel", [((530, 140, 1), MS8), ((530, 140, 1), TL8), ((530, 140, 1), B.KERNEL_FUSED),
+                                         ((41, 27, 19), B.KERNEL_FUSED), ((41, 27, 19), B.KERNEL_SPLIT)])
+def test_grid_of_one_non_default_material(oracle, dims, kernel):
+    """Every cell holds tissue code 4: the single-material kernels run with that material's row;
+    then the row changes; then one cell takes another code and the table kernels are back."""
+    src = [(dims[0] // 2, dims[1] // 2, dims[2] // 2)]
+    s, o = util.pair(oracle, dims, src, CON, kernel=kernel, sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    codes = np.full(dims[::-1], 4, dtype=np.uint8)
+    util.set_materials(s, o, codes)
+    assert util.run_and_compare(s, o, 40, 20, "one material") == 0
+    s.set_material(4, 0.3, 30.0, 12.0, 1.5e-11)          # the row behind the single code changes
+    table = util.RIKEN_LIKE.copy()
+    table[4] = [0.3, 30.0, 12.0, 1.5e-11]
+    o.set_materials(codes, table)
+    assert util.run_and_compare(s, o, 24, 12, "one material, new row") == 0
+    codes[..., dims[1] // 3, dims[0] // 3] = 2
+    s.set_codes(codes)
+    o.set_materials(codes, table)
+    assert util.run_and_compare(s, o, 30, 15, "two materials") == 0
+
+
 # ------------------------------------------------------------------ results path
 
 @pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS5, TL1, TL3, TL8])

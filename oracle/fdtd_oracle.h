@@ -20,9 +20,12 @@
  *    100^3 vacuum case): tests/golden/survey_known_answers.json and
  *    tests/test_oracle_golden.py (CPU only).  They are the only pins of the
  *    input surface (parameter parse, source waveform, rp formula).
- * UNPINNED: the 2-D TMz reduction (the reference has no 2-D mode: with nz = 1
- * none of its guards passes) and the CONSISTENT coefficient variant, which are
- * defined by this restatement.
+ * The 2-D TMz reduction (the reference has no 2-D mode: with nz = 1 none of its
+ * guards passes) is pinned step by step: one step of it is what the reference's
+ * kernels do to the middle plane of a three-plane grid whose state does not
+ * depend on z (same test file, last test).
+ * UNPINNED: the CONSISTENT coefficient variant (one expression, d = a + b -
+ * sigma dt^2), which is defined by this restatement.
  *
  * Every function cites the reference file:line it follows.  Arithmetic follows
  * the reference's C promotions (fp32 fields, fp64 in-flight in the E update)

@@ -6,9 +6,11 @@ image's hipify-perl (cuda* runtime names -> hip*, nothing else) and compiled for
 (oracle/ref_driver.hip launches the five kernels with main's geometry, order and buffer
 rotation).  These tests pin the oracle to it bit for bit -- vacuum, Debye tissue maps, random rp
 planes (all twelve Mur cases), sources, odd extents, every phase of the three-buffer rotation --
-and hold the HIP kernels against the same outputs directly.  The 2-D TMz reduction has no
-counterpart in the reference (with nz = 1 none of its guards passes) and stays defined by the
-oracle."""
+and hold the HIP kernels against the same outputs directly.  The reference has no 2-D mode (with
+nz = 1 none of its guards passes), but ONE step of the 2-D TMz reduction is what the reference's
+kernels do to the middle plane of a three-plane grid whose state does not depend on z and has
+ex = ey = hz = dx = dy = 0: the z differences the reduction drops are then exact zeros.  The last
+test pins the oracle's 2-D step to that, from random states."""
 import os
 
 import numpy as np
@@ -124,3 +126,44 @@ def test_hip_kernels_equal_reference_kernels(oracle, ref, kernel):
         for level in ((0,) if fid <= B.HZ else (0, 1)):
             util.assert_bits_equal(s.field(fid, level), got[fid][level], f"{B.FIELD_NAMES[fid]} level {level}")
     assert np.abs(s.field(B.EZ)).max() > 0
+
+
+@pytest.mark.parametrize("dims,warm,seed", [((37, 29), 0, 1), ((37, 29), 1, 2), ((37, 29), 2, 3), ((131, 6), 4, 4),
+                                            ((3, 3), 0, 5), ((5, 40), 5, 6)])
+def test_2d_tmz_step_is_the_reference_step_of_a_z_uniform_state(oracle, ref, dims, warm, seed):
+    """hx, hy, dz, ez of a random 2-D state (tissue codes, random rp planes, sources, all three
+    buffers filled) go into every plane of an nx x ny x 3 grid, the other components are zero; one
+    step of the reference's kernels on that grid, and plane 1 must be the oracle's 2-D step: every
+    buffer of hx, hy, dz, ez, bit for bit.  Every phase of the buffer rotation is covered."""
+    nx, ny = dims
+    rng = np.random.default_rng(seed)
+    srcs2 = [(nx // 2, ny // 2, 0), (1, 1, 0)]
+    kw = dict(sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    o2 = oracle.Oracle(oracle.make_params(nx, ny, 1, srcs2, **kw), ecoef=oracle.ECOEF_REFERENCE)
+    o3 = oracle.Oracle(oracle.make_params(nx, ny, 3, [(x, y, 1) for x, y, _ in srcs2], **kw), ecoef=oracle.ECOEF_REFERENCE)
+    codes = rng.integers(0, len(util.RIKEN_LIKE), size=(ny, nx), dtype=np.uint8)
+    o2.set_materials(codes[None], util.RIKEN_LIKE)
+    o3.set_materials(np.repeat(codes[None], 3, axis=0), util.RIKEN_LIKE)
+    # x faces: [z][y][2]; y faces: [z][2][x] -- the 2-D planes repeated for every z
+    for face in (0, 1, 3, 4):
+        rp = (1.0 + 60.0 * rng.random(o2.rp(face).size)).astype(np.float32)
+        o2.set_rp(face, rp)
+        o3.set_rp(face, np.tile(rp, 3))
+    if warm:                       # only to move both step counters (source sample, buffer rotation)
+        o2.step(warm)
+        o3.step(warm)
+    for fid in range(9):
+        for level in ((0,) if fid <= B.HZ else (0, 1, 2)):
+            if fid in (B.HX, B.HY, B.DZ, B.EZ):
+                amp = 1e-12 if fid == B.DZ else (1e-3 if fid <= B.HZ else 1.0)
+                plane = (rng.standard_normal((ny, nx)) * amp).astype(np.float32)
+                o2.set_field(fid, plane[None], level)
+                o3.set_field(fid, np.repeat(plane[None], 3, axis=0), level)
+            else:
+                o3.set_field(fid, np.zeros((3, ny, nx), dtype=np.float32), level)
+    got = ref.run_like(o3, 1)
+    o2.step(1)
+    for fid in (B.HX, B.HY, B.DZ, B.EZ):
+        for level, arr in enumerate(got[fid]):
+            util.assert_bits_equal(arr[1], np.asarray(o2.field(fid, level))[0], f"{oracle.FIELD_NAMES[fid]} level {level}")
+    assert np.abs(np.asarray(o2.field(B.EZ))).max() > 0

@@ -203,7 +203,7 @@ def test_3d_upsampled_pgm_slices_expanded_on_the_device(oracle, tmp_path):
 
 
 @pytest.mark.parametrize("kind", [B.KERNEL_MULTISTEP, B.KERNEL_TILE])
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDTD_TEST_SEEDS", "24"))))   # more seeds for a soak run
 def test_2d_multi_step_random_cases(oracle, seed, kind):
     """Seeded random cases of the multi-step sweep: grid size (strip and band edges included),
     steps per pass, sources (also on the last column and row), tissue maps, rp planes, state and
@@ -347,6 +347,42 @@ def test_rccl_binding_with_a_one_rank_communicator():
     s3.step(20)
     s3.comm_init(B.comm_unique_id(), 0, 1)
     s3.comm_selftest()
+
+
+@pytest.mark.parametrize("kind", [B.KERNEL_MULTISTEP, B.KERNEL_TILE])
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDTD_TEST_WIDE_SEEDS", "6"))))
+def test_2d_multi_step_random_cases_many_strips_and_bands(oracle, seed, kind):
+    """Wider and taller random grids: several strips and bands per launch, so that the order in which
+    the row-marching sweep starts its waves (x-face strips, last band, waves with sources or
+    probes first) and the tile map of the tiled sweep matter; sources and probes anywhere, tissue
+    codes, rp planes; fields and probe rows bit for bit."""
+    rng = np.random.default_rng(5000 + seed)
+    nx, ny = int(rng.integers(481, 2600)), int(rng.integers(100, 900))
+    k = int(rng.integers(2, 9))
+    srcs = [(int(rng.integers(1, nx)), int(rng.integers(1, ny)), 0) for _ in range(int(rng.integers(1, 6)))]
+    s, o = util.pair(oracle, (nx, ny, 1), srcs, CON, kernel=(kind, k), sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    if rng.random() < 0.6:
+        codes = rng.integers(0, len(util.RIKEN_LIKE), size=(1, ny, nx), dtype=np.uint8)
+        util.set_materials(s, o, codes)
+    for face in (0, 1, 3, 4):
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    util.randomize(s, o, rng, oracle)
+    probes = [[int(rng.integers(0, nx)), int(rng.integers(0, ny)), 0] for _ in range(int(rng.integers(1, 17)))]
+    s.set_probes(probes, capacity=64)
+    steps = [int(v) for v in rng.integers(1, 2 * k + 2, size=3)]
+    series = []
+    peak = util.Peak()
+    for n in steps:
+        for _ in range(n):
+            o.step(1, threads=8)
+            peak.update(o, util.fields_of(s))
+            series.append([[o.field(f)[0, y, x] for f in (B.HX, B.HY, B.DZ, B.EZ)] for x, y, _ in probes])
+        s.step(n)
+        assert util.compare(s, o, peak, f"seed {seed} {nx}x{ny} K {k}") == 0
+    got = s.read_probes(0, len(series))
+    assert np.array_equal(got.view(np.uint32), np.array(series, dtype=np.float32).view(np.uint32))
 
 
 @pytest.mark.timeout(300)

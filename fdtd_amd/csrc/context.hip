@@ -116,6 +116,7 @@ struct fdtd_ctx {
     int one_code = 0;  // the device code behind table0: 0 (the defaults), or the single code of a whole grid
     int ntab_halo = 1; // the same for the material codes received into the deep halo rows
     int halo_top[2] = {0, 0};
+    bool rp_from_codes = false; // x-face rp entries of the deep halo rows follow the codes that arrive there
     bool spp_fixed = false; // steps per pass do not depend on the materials (slabs, or set by the caller)
     int ntab_eff() const { return std::max(ntab, ntab_halo); }
     std::vector<uint8_t> codes_host; // slab cells, x fastest; empty = all default (or kept as codes_base)
@@ -412,6 +413,29 @@ int top_code(const uint8_t *codes, size_t n)
     return top;
 }
 
+// The code bytes (depth rows of nx, as stored on the device) that arrived for the halo rows on
+// `side`.  They decide the kernel variant; and where the rp planes follow the loaded materials, the
+// x-face entries of those rows -- which the slab recomputes, Mur included -- are derived from them.
+int note_halo_codes(fdtd_ctx *c, int side, const uint8_t *codes)
+{
+    const int depth = c->tb_steps, nx = c->nx;
+    c->halo_top[side] = top_code(codes, (size_t)depth * nx);
+    c->ntab_halo = 1 + std::max(c->halo_top[0], c->halo_top[1]);
+    if (!c->rp_from_codes) return 0;
+    auto row_of = [&](uint8_t dev) -> const MaterialRow & { return c->mats[dev == 0 ? kDefaultCode : dev - 1]; };
+    for (int r = 0; r < depth; ++r) {
+        const int y = side == 0 ? c->s0 - depth + r : c->s0 + c->sn + r;
+        if (y < 0 || y >= c->gn) continue;
+        for (int k = 0; k < 2; ++k) {
+            c->rp_host[FDTD_RP_X0][(size_t)y * 2 + k] = rp_value(c->p, row_of(codes[(size_t)r * nx + k]), true);
+            c->rp_host[FDTD_RP_XEND][(size_t)y * 2 + k] =
+                rp_value(c->p, row_of(codes[(size_t)r * nx + nx - 2 + k]), true);
+        }
+    }
+    int rc = upload_rp(c, FDTD_RP_X0);
+    return rc ? rc : upload_rp(c, FDTD_RP_XEND);
+}
+
 // Halo exchange with ranks rank-1 and rank+1 over the communicator, queued on `st`.
 // `scan`: the materials may have changed since the last exchange, so look at the codes that
 // arrive (this waits for the exchange): a slab whose own cells all hold one material must still
@@ -439,15 +463,15 @@ int exchange_halos(fdtd_ctx *c, hipStream_t st, bool scan)
         if (scan) {
             const size_t n = (size_t)c->tb_steps * c->nx;
             std::vector<uint8_t> tmp(n);
+            c->halo_top[0] = c->halo_top[1] = 0;
+            c->ntab_halo = 1;
             for (int s = 0; s < 2; ++s) {
-                c->halo_top[s] = 0;
                 if (!((sides >> s) & 1)) continue;
                 HIPCHK(hipMemcpyAsync(tmp.data(), (const uint8_t *)(c->halo_recv[s] + (size_t)6 * n), n,
                                       hipMemcpyDeviceToHost, st));
                 HIPCHK(hipStreamSynchronize(st));
-                c->halo_top[s] = top_code(tmp.data(), n);
+                if ((rc = note_halo_codes(c, s, tmp.data()))) return rc;
             }
-            c->ntab_halo = 1 + std::max(c->halo_top[0], c->halo_top[1]);
         }
         return 0;
     }
@@ -1386,6 +1410,7 @@ int fdtd_set_rp(fdtd_ctx *c, int face, const float *data, size_t count)
     }
     if (use_device(c)) return -10;
     c->rp_host[face].assign(data, data + count);
+    if (face == FDTD_RP_X0 || face == FDTD_RP_XEND) c->rp_from_codes = false; // the caller's plane stands
     return upload_rp(c, face);
 }
 
@@ -1401,14 +1426,14 @@ int fdtd_get_rp(fdtd_ctx *c, int face, float *data, size_t count)
 
 int fdtd_setup_mur_from_materials(fdtd_ctx *c)
 {
+    if (use_device(c)) return -10;
     if (c->deep() && c->sn != c->gn) {
         // a multi-step slab also applies the Mur update to the neighbours' rows it recomputes in its
-        // halos, and it does not hold their materials on the host
-        set_error("fdtd_setup_mur_from_materials: not available on a slab of the multi-step mode (set the planes "
-                  "with fdtd_set_rp, or use FDTD_KERNEL_FUSED)");
-        return -3;
+        // halos: their x-face entries are derived from the material codes that arrive with the next
+        // exchange, which this call makes due
+        c->rp_from_codes = true;
+        c->halo_stale = true;
     }
-    if (use_device(c)) return -10;
     const int nx = c->nx, ny = c->ny, nz = c->nz;
     // A slab fills in the entries of the cells it holds -- the only ones its Mur launches look at;
     // the rest of its planes keeps the values derived from the defaults.
@@ -1780,8 +1805,8 @@ static int halo_copy(fdtd_ctx *c, int side, float *host, size_t count, bool get,
                 return rc;
             // the neighbour's material codes travel with the rows: they decide the kernel variant
             const size_t n = (size_t)c->tb_steps * c->nx;
-            c->halo_top[side] = top_code((const uint8_t *)(host + (size_t)6 * n), n);
-            c->ntab_halo = 1 + std::max(c->halo_top[0], c->halo_top[1]);
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if ((rc = note_halo_codes(c, side, (const uint8_t *)(host + (size_t)6 * n)))) return rc;
         }
         HIPCHK(hipStreamSynchronize(c->stream));
         return 0;

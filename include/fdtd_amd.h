@@ -156,7 +156,11 @@ int fdtd_get_rp(fdtd_ctx *ctx, int face, float *data, size_t count);
  * (opt-in: the reference only ever evaluates it on the defaults).  A slab
  * fills in the entries of the cells it holds, which are the only ones its Mur
  * updates read; the other entries of its planes keep the default-derived
- * values (fdtd_get_rp returns them as such). */
+ * values (fdtd_get_rp returns them as such).  A slab of the multi-step mode
+ * also recomputes the neighbours' rows in its halos, Mur included: their x-face
+ * entries are taken from the material codes that arrive with the next halo
+ * exchange, which this call makes due (host-staged exchange: do it before the
+ * next fdtd_step). */
 int fdtd_setup_mur_from_materials(fdtd_ctx *ctx);
 
 /* ---- time stepping ---------------------------------------------------- */

@@ -261,6 +261,12 @@ def test_2d_slabs_equal_whole_grid(oracle, kernel, world, blank):
         if not (blank and i == 1):
             sv.set_codes(codes[b:b + n])
     assert len({sv.steps_per_pass for sv in slabs}) == 1
+    if world == 3:
+        # rp planes from the loaded materials: a multi-step slab takes the x-face entries of the
+        # neighbours' rows it recomputes from the codes that arrive with the halos
+        for sv in [whole] + slabs:
+            sv.setup_mur_from_materials()
+
     def exchange():
         for r in range(world - 1):          # neighbours r and r + 1
             up, down = slabs[r].halo_get(1), slabs[r + 1].halo_get(0)

@@ -150,11 +150,13 @@ def test_3d_slabs_on_threads_equal_oracle(oracle, monkeypatch, kernel, overlap):
         group.close()
 
 
-@pytest.mark.parametrize("dims,kernel", [((44, 23, 31), B.KERNEL_FUSED), ((300, 90, 1), MS3), ((300, 90, 1), B.KERNEL_FUSED)])
+@pytest.mark.parametrize("dims,kernel", [((44, 23, 31), B.KERNEL_FUSED), ((300, 90, 1), MS3), ((300, 90, 1), MS8),
+                                         ((300, 90, 1), TL8), ((300, 90, 1), B.KERNEL_FUSED)])
 def test_rp_planes_from_loaded_materials_per_slab(oracle, monkeypatch, dims, kernel):
     """fdtd_setup_mur_from_materials on slabs: every slab derives the rp entries of the cells it
-    holds (the only ones its Mur launches read); the run equals the oracle with setupMurBoundary
-    evaluated on the whole loaded grid."""
+    holds (the only ones its Mur launches read) -- a multi-step slab also the x-face entries of the
+    neighbours' rows it recomputes, from the material codes that arrive with the halos; the run
+    equals the oracle with setupMurBoundary evaluated on the whole loaded grid."""
     nx, ny, nz = dims
     world, steps = 3, 36
     rng = np.random.default_rng(23)
@@ -162,12 +164,6 @@ def test_rp_planes_from_loaded_materials_per_slab(oracle, monkeypatch, dims, ker
     srcs = [(nx // 2, ny // 2, nz // 2), (3, 3, 0 if nz == 1 else 2)]
     slabs, parts, group = build_slabs(monkeypatch, dims, srcs, kernel, world, True, codes, default_slab=-1)
     try:
-        if kernel == MS3:
-            # a multi-step slab recomputes its neighbours' boundary rows, Mur included, and does not
-            # hold their materials on the host: it says so
-            with pytest.raises(fdtd_amd.FdtdError, match="multi-step"):
-                slabs[0].setup_mur_from_materials()
-            return
         for sv in slabs:
             sv.setup_mur_from_materials()
 

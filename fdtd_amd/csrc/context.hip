@@ -36,6 +36,7 @@ using namespace fdtd;
 
 namespace {
 constexpr size_t kSlack = 256; // floats (or bytes) of zero padding around each array
+constexpr long kFoldMurCells = 2500000; // 3-D grids up to this size take the Mur faces into the sweep
 
 // Staging memory of fdtd_halo_get_noalloc(): lives in the code object, so the entry point never
 // allocates.  Every GPU the library runs on holds its own copy (4 MiB) at its own address; the
@@ -98,6 +99,7 @@ struct fdtd_ctx {
     MatEntry table0 = {};
     float *rp[6] = {};
     size_t rp_n[6] = {};
+    float *mur_cf[6] = {}; // fold_mur: four Mur factors per face cell, kept in step with rp[]
 
     int cur = 0;  // slot of the newest E/D level inside the current pair
     int pair = 0; // which pair of E/D arrays holds the two live levels
@@ -161,6 +163,7 @@ struct fdtd_ctx {
     float *halo_send[2] = {}, *halo_recv[2] = {};
     bool auto_kernel = false;
     bool interleave3 = false; // 3-D: the three components of a field share one allocation, row by row
+    bool fold_mur = false;    // 3-D fused sweep on a small whole grid: the Mur faces inside the sweep
     bool probe_pending = false; // inside fdtd_step(): the newest step's probe row is still to be written
     bool halo_stale = true; // set by everything that changes the state behind the stepper's back
     bool deep() const { return kernel == FDTD_KERNEL_MULTISTEP; }
@@ -277,6 +280,27 @@ int upload_rp(fdtd_ctx *c, int face)
 {
     HIPCHK(hipMemcpyAsync(c->rp[face], c->rp_host[face].data(), c->rp_n[face] * sizeof(float),
                           hipMemcpyHostToDevice, c->stream));
+    if (c->fold_mur) {
+        // the sweep that finishes the faces itself reads the field-independent factors of the Mur
+        // update, taken from the plane here, instead of the plane
+        if (!c->mur_cf[face]) {
+            int rc = dev_alloc(c, &c->mur_cf[face], c->rp_n[face] * 2);
+            if (rc) return rc;
+        }
+        MurCoefs m;
+        m.rp = c->rp[face];
+        m.cf = c->mur_cf[face];
+        m.face = face;
+        m.nx = c->nx;
+        m.ny = c->ny;
+        m.nz = c->nz;
+        m.dt = c->p.dt;
+        m.du = face % 3 == 0 ? c->p.dx : face % 3 == 1 ? c->p.dy : c->p.dz;
+        m.mu0 = c->p.mu0;
+        m.eps0 = c->p.eps0;
+        launch_mur_coefs(m, c->stream);
+        HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -674,6 +698,8 @@ int step_once(fdtd_ctx *c, bool last)
             f.ring = nullptr;
             f.probe_slot = 0;
             f.probes = c->probes;
+            f.mur = c->fold_mur ? 1 : 0;
+            for (int face = 0; face < 6; ++face) f.cf[face] = c->mur_cf[face];
             for (int s = 0; s < a.src.count; ++s) {
                 const int kz = a.src.z[s] - c->s0;
                 const bool here = kz >= 0 && kz < c->sn;
@@ -708,7 +734,7 @@ int step_once(fdtd_ctx *c, bool last)
         if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream));
         m.k_begin = lo;
         m.k_end = hi;
-        launch_mur3d(m, c->stream);
+        if (!(c->kernel == FDTD_KERNEL_FUSED && c->fold_mur)) launch_mur3d(m, c->stream);
     }
     HIPCHK(hipGetLastError());
     if (prof) c->prof_steps[c->prof_n++] = 1;
@@ -1169,6 +1195,14 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     // of ez, then row y + 1 ...): 8 runs of memory per sweep instead of 24 (FDTD_3D_INTERLEAVE=0: apart).
     c->interleave3 = !c->is2d() && c->kernel == FDTD_KERNEL_FUSED;
     if (const char *v = std::getenv("FDTD_3D_INTERLEAVE")) c->interleave3 = c->interleave3 && std::atoi(v) != 0;
+    // Small 3-D grids: a step is the sweep and the Mur launch, and the Mur launch -- 5 us whatever the
+    // grid -- is a sixth of a 100^3 step; the sweep finishes the faces itself there (two waves per
+    // SIMD, which costs a large grid more than the launch it saves).  FDTD_3D_FOLD_MUR=0/1 overrides.
+    c->fold_mur = !c->is2d() && c->kernel == FDTD_KERNEL_FUSED && c->sn == c->gn && c->nx >= 4 && c->ny >= 4 &&
+                  c->nz >= 4 && (long)c->nx * c->ny * c->nz <= kFoldMurCells;
+    if (const char *v = std::getenv("FDTD_3D_FOLD_MUR"))
+        c->fold_mur = std::atoi(v) != 0 && !c->is2d() && c->kernel == FDTD_KERNEL_FUSED && c->sn == c->gn &&
+                      c->nx >= 4 && c->ny >= 4 && c->nz >= 4;
     c->pitch = interleave ? 6 * row_pitch : c->interleave3 ? 3 * row_pitch : row_pitch;
     c->cpitch = row_pitch;
     c->rows_store = c->is2d() ? (size_t)c->sn + 2 * c->halo : ((size_t)c->sn + 2) * c->ny;

@@ -214,6 +214,22 @@ struct Fused3D {
     float *ring;                           // nullptr: nothing to record
     int probe_slot;
     ProbeList probes;
+    // Small whole grids: updateMurBoundary inside the sweep, a launch less per step.  The thread that
+    // owns the cell next to a face cell finishes that face cell (it holds both time levels of its own
+    // cell and E^n of the face cell); the owner of the face cell leaves that component alone.
+    int mur;                               // 0: fdtd3d_mur follows the sweep
+    const float *cf[6];                    // per face cell the four factors of MurCoefs (16-byte entries)
+};
+
+// The field-independent part of the Mur update of one face, taken once when its rp plane changes:
+// cf[cell] = mur_coefs(...) of the face cell and the cell one step inside.  Face cells are numbered
+// z * ny + y (x faces), z * nx + x (y faces), y * nx + x (z faces).
+struct MurCoefs {
+    const float *rp;
+    float *cf;
+    int face;   // FDTD_RP_*
+    int nx, ny, nz;
+    float dt, du, mu0, eps0;
 };
 
 // Deep halo exchange of the multi-step mode: `depth` rows of every live array (H, both E and D
@@ -272,6 +288,7 @@ void launch_mur2d(const Mur2D &a, void *stream);
 void launch_h3d(const Sweep3D &a, void *stream);
 void launch_de3d(const Sweep3D &a, void *stream);
 void launch_mur3d(const Mur3D &a, void *stream);
+void launch_mur_coefs(const MurCoefs &a, void *stream);
 void launch_halo_deep(const HaloDeep &a, void *stream);
 void launch_expand_codes(const ExpandCodes &a, void *stream);
 void launch_probe2d(const Probe2D &a, void *stream);

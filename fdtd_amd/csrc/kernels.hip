@@ -260,6 +260,28 @@ __global__ __launch_bounds__(256) void fdtd3d_mur(const Mur3D a)
     }
 }
 
+__global__ __launch_bounds__(256) void fdtd3d_mur_coefs(const MurCoefs a)
+{
+    const int axis = a.face % 3;
+    const bool high = a.face >= 3;
+    const long n = axis == 0 ? (long)a.ny * a.nz : axis == 1 ? (long)a.nx * a.nz : (long)a.nx * a.ny;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    float r0, r1; // the two rp entries of the cell pair, lower index first (layouts of fdtd.cu:952-1001)
+    if (axis == 0) {
+        r0 = a.rp[t * 2];
+        r1 = a.rp[t * 2 + 1];
+    } else if (axis == 1) {
+        const long z = t / a.nx, x = t % a.nx;
+        r0 = a.rp[z * 2 * a.nx + x];
+        r1 = a.rp[z * 2 * a.nx + x + a.nx];
+    } else {
+        r0 = a.rp[t];
+        r1 = a.rp[t + (long)a.nx * a.ny];
+    }
+    ((f4 *)a.cf)[t] = mur_coefs(a.dt, a.du, a.mu0, a.eps0, high ? r1 : r0, high ? r0 : r1);
+}
+
 // ------------------------------------------------------------------ probes
 
 __global__ void fdtd2d_probe(const Probe2D a)
@@ -393,6 +415,13 @@ void launch_mur3d(const Mur3D &a, void *stream)
 void launch_halo_deep(const HaloDeep &a, void *stream)
 {
     hipLaunchKernelGGL(fdtd2d_halo_deep, dim3((a.nx + 255) / 256, 2 * 7 * a.depth), dim3(256), 0, S(stream), a);
+}
+
+void launch_mur_coefs(const MurCoefs &a, void *stream)
+{
+    const int axis = a.face % 3;
+    const long n = axis == 0 ? (long)a.ny * a.nz : axis == 1 ? (long)a.nx * a.nz : (long)a.nx * a.ny;
+    hipLaunchKernelGGL(fdtd3d_mur_coefs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), a);
 }
 
 void launch_expand_codes(const ExpandCodes &a, void *stream)

@@ -52,7 +52,7 @@ __device__ __forceinline__ f4 shift_right(f4 v, int lane, float edge)
     return r;
 }
 
-template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_sweep(const Fused3D a)
+template <bool ONE, int W, bool MUR> __global__ __launch_bounds__(256, W) void fdtd3d_sweep(const Fused3D a)
 {
     const Grid3D &g = a.g;
     const int lane = threadIdx.x & 63;
@@ -104,6 +104,34 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
         const unsigned c0 = (unsigned)__builtin_amdgcn_readfirstlane((int)cd) & 0xffu;
         uniform = __all(cd == c0 * 0x01010101u);
         if (uniform) mu = a.table[c0];
+    }
+
+    // Mur factors of the x faces next to this word: every wave holds such words, so they are asked for
+    // here, ahead of the field loads, not behind the E update
+    int hi_cell = -1; // which of the four cells is nx-2
+    f4 cfx0 = {0.f, 0.f, 0.f, 0.f}, cfxe = cfx0;
+    if (MUR && act) {
+        const size_t fx = (size_t)(g.gz0 + k) * g.ny + y;
+        if (x4 == 0) cfx0 = ((const f4 *)a.cf[FDTD_RP_X0])[fx];
+        if (g.nx - 2 >= x4 && g.nx - 2 < x4 + 4) {
+            hi_cell = g.nx - 2 - x4;
+            cfxe = ((const f4 *)a.cf[FDTD_RP_XEND])[fx];
+        }
+    }
+    // the same for the y and z faces (whole rows and planes of words; rows 1 and ny-2, planes 1 and
+    // gnz-2 are distinct: ny, nz >= 4)
+    f4 cfy[4], cfz[4];
+    if (MUR) {
+        const int zz = g.gz0 + k;
+        const bool ynear = act && (y == 1 || y == g.ny - 2), znear = act && (zz == 1 || zz == g.gnz - 2);
+        const f4 *py = (const f4 *)(y == 1 ? a.cf[FDTD_RP_Y0] : a.cf[FDTD_RP_YEND]) + (size_t)zz * g.nx;
+        const f4 *pz = (const f4 *)(zz == 1 ? a.cf[FDTD_RP_Z0] : a.cf[FDTD_RP_ZEND]) + (size_t)y * g.nx;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f4 zero = {0.f, 0.f, 0.f, 0.f};
+            cfy[i] = (ynear && x4 + i < g.nx) ? py[x4 + i] : zero;
+            cfz[i] = (znear && x4 + i < g.nx) ? pz[x4 + i] : zero;
+        }
     }
 
     // E^n and old H: own row and the rows below in y and z (and the two diagonals)
@@ -231,6 +259,64 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
         en[2][i] = g_eyz ? e_update(m, g.dt, ez_c[i], e1[2][i], dn[2][i], d0[2][i], d1[2][i]) : e1[2][i];
     }
 
+    // updateMurBoundary, fdtd_calculations.cu:216-428, for the face cells next to this thread's cells.
+    // A face value needs E^{n+1} and E^n of the cell one step inside (this thread's) and E^n of the
+    // face cell (a neighbour word loaded for the H update above).  No cell that is one step inside a
+    // face is itself finished by a Mur case of the same component, so en[] is final here.
+    unsigned skip[3] = {0u, 0u, 0u}; // cells of the own word that another Mur case finishes
+    if (MUR && act) {
+        const bool y_in = y_lo && y_hi, z_in = z_lo && z_hi;
+        const bool y_face = y == 0 || y == g.ny - 1, z_face = z == 0 || z == g.gnz - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x4 + i;
+            const bool x_in = x_lo[i] && x_hi[i], x_face = x == 0 || x == g.nx - 1;
+            if ((y_face && x_hi[i] && z_in) || (z_face && x_hi[i] && y_in)) skip[0] |= 1u << i;
+            if ((x_face && y_hi && z_in) || (z_face && x_in && y_hi)) skip[1] |= 1u << i;
+            if ((x_face && y_in && z_hi) || (y_face && x_in && z_hi)) skip[2] |= 1u << i;
+        }
+        // x faces: ey (:303-329) and ez (:369-395)
+        if (x4 == 0) { // cell 1 is one step inside the low face, cell 0 on it
+            if (y_hi && z_in) a.e_w[1][o] = mur_apply(cfx0, en[1][1], ey_c[1], ey_c[0]);
+            if (y_in && z_hi) a.e_w[2][o] = mur_apply(cfx0, en[2][1], ez_c[1], ez_c[0]);
+        }
+        if (hi_cell >= 0) {
+            auto pick = [&](const f4 &v) { return hi_cell == 0 ? v.x : hi_cell == 1 ? v.y : hi_cell == 2 ? v.z : v.w; };
+            const float ey_in = pick(ey_c), ez_in = pick(ez_c);
+            // the high face takes eySource for both interior terms (:323, :325)
+            if (y_hi && z_in) a.e_w[1][o + hi_cell + 1] = mur_apply(cfxe, ey_in, ey_in, pick(ey_px));
+            if (y_in && z_hi) a.e_w[2][o + hi_cell + 1] = mur_apply(cfxe, pick(en[2]), ez_in, pick(ez_px));
+        }
+        // y faces: ex (:237-263) and ez (:401-427); rows 1 and ny-2 are distinct (ny >= 4)
+        if (y == 1 || y == g.ny - 2) {
+            const bool low = y == 1;
+            const f4 exf = low ? ex_my : ex_py, ezf = low ? ez_my : ez_py;
+            const size_t fo = low ? o - rs : o + rs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x4 + i;
+                if (x >= g.nx) continue;
+                const f4 cf = cfy[i];
+                if (x_hi[i] && z_in) a.e_w[0][fo + i] = mur_apply(cf, en[0][i], ex_c[i], exf[i]);
+                if (x_lo[i] && x_hi[i] && z_hi) a.e_w[2][fo + i] = mur_apply(cf, en[2][i], ez_c[i], ezf[i]);
+            }
+        }
+        // z faces: ex (:269-295) and ey (:335-361); planes 1 and gnz-2 are distinct (nz >= 4)
+        if (z == 1 || z == g.gnz - 2) {
+            const bool low = z == 1;
+            const f4 exf = low ? ex_mz : ex_pz, eyf = low ? ey_mz : ey_pz;
+            const size_t fo = low ? o - ps : o + ps;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x4 + i;
+                if (x >= g.nx) continue;
+                const f4 cf = cfz[i];
+                if (x_hi[i] && y_in) a.e_w[0][fo + i] = mur_apply(cf, en[0][i], ex_c[i], exf[i]);
+                if (x_lo[i] && x_hi[i] && y_hi) a.e_w[1][fo + i] = mur_apply(cf, en[1][i], ey_c[i], eyf[i]);
+            }
+        }
+    }
+
     if (act) {
         st4_stream(a.h_w[0] + o, hx_n);
         st4_stream(a.h_w[1] + o, hy_n);
@@ -238,7 +324,13 @@ template <bool ONE, int W> __global__ __launch_bounds__(256, W) void fdtd3d_swee
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             st4_stream(a.d_w[c] + o, dn[c]);
-            st4_stream(a.e_w[c] + o, en[c]);
+            if (!MUR || skip[c] == 0u) {
+                st4_stream(a.e_w[c] + o, en[c]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (!((skip[c] >> i) & 1u)) a.e_w[c][o + i] = en[c][i];
+            }
         }
         // the H halo plane below a slab is kept current here, so H is never exchanged
         if (k == 0 && g.has_lower) {
@@ -257,17 +349,20 @@ void launch_sweep3d(const Fused3D &a, void *stream)
     const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)(a.k_end - a.k_begin) + (a.ring ? 1u : 0u));
     const dim3 block((unsigned)a.block);
     static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 3;
-#define GO(W)                                                                                     \
-    do {                                                                                          \
-        if (a.ntab == 1)                                                                          \
-            hipLaunchKernelGGL((fdtd3d_sweep<true, W>), grid, block, 0, (hipStream_t)stream, a);  \
-        else                                                                                      \
-            hipLaunchKernelGGL((fdtd3d_sweep<false, W>), grid, block, 0, (hipStream_t)stream, a); \
+#define GO(W, MUR)                                                                                     \
+    do {                                                                                               \
+        if (a.ntab == 1)                                                                               \
+            hipLaunchKernelGGL((fdtd3d_sweep<true, W, MUR>), grid, block, 0, (hipStream_t)stream, a);  \
+        else                                                                                           \
+            hipLaunchKernelGGL((fdtd3d_sweep<false, W, MUR>), grid, block, 0, (hipStream_t)stream, a); \
     } while (0)
-    if (waves == 2)
-        GO(2);
+    // the Mur cases keep the neighbour words of the H update alive to the end: two waves per SIMD
+    if (a.mur)
+        GO(2, true);
+    else if (waves == 2)
+        GO(2, false);
     else
-        GO(3);
+        GO(3, false);
 #undef GO
 }
 

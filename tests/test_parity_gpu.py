@@ -43,13 +43,17 @@ def test_3d_vacuum_fields_match_oracle(oracle, kernel):
     assert util.run_and_compare(s, o, 90, 30, "100^3 vacuum") == 0
 
 
-@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, B.KERNEL_SPLIT])
+@pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, "fused, Mur launch", B.KERNEL_SPLIT])
 @pytest.mark.parametrize("dims,ecoef", [((23, 19, 17), REF), ((23, 19, 17), CON), ((64, 5, 9), CON),
                                          ((3, 3, 3), REF), ((130, 7, 4), REF), ((265, 12, 6), CON),
-                                         ((300, 9, 5), CON)])
-def test_3d_random_state_debye_and_mur(oracle, dims, ecoef, kernel):
+                                         ((300, 9, 5), CON), ((4, 4, 4), REF), ((5, 4, 6), CON)])
+def test_3d_random_state_debye_and_mur(oracle, monkeypatch, dims, ecoef, kernel):
     """Random fields, random tissue map, non-uniform rp planes, two sources: every
-    term of every kernel (all 12 Mur cases, the ey high-x quirk) is exercised."""
+    term of every kernel (all 12 Mur cases, the ey high-x quirk) is exercised.  Grids of this size
+    finish the Mur faces inside the fused sweep; "Mur launch" runs the sweep large grids take."""
+    if kernel == "fused, Mur launch":
+        monkeypatch.setenv("FDTD_3D_FOLD_MUR", "0")
+        kernel = B.KERNEL_FUSED
     nx, ny, nz = dims
     rng = np.random.default_rng(1234 + nx)
     srcs = [(nx // 2, ny // 2, nz // 2), (nx - 1, ny - 1, nz - 1), (1, 1, 0)]

@@ -204,7 +204,8 @@ struct Fused3D {
     float jz;
     int k_begin, k_end;                    // local planes this launch covers
     long long plane_words;                 // 16-byte words of one plane: ny * pitch / 4
-    int seg_words;                         // words of one XCD's segment of a plane (plane_words / 8, rounded up)
+    int flat;                              // planes per segment space: 1, or all planes of the launch (small grids)
+    int seg_words;                         // words of one XCD's segment of a space (an eighth of it, rounded up to waves)
     int seg_blocks;                        // blocks per segment
     int block;                             // threads per block: 256, or 64 / 128 where 256 would leave waves idle
     long long src_word[FDTD_MAX_SOURCES];  // word holding the source cell, -1 if another slab holds it

@@ -79,13 +79,19 @@ template <bool ONE, int W, bool MUR> __global__ __launch_bounds__(256, W) void f
     // lines of plane z-1 and z+1 it needs are the ones it pulled into its own L2 a plane ago.
     const int p4 = g.rowlen >> 2;
     const unsigned xcd = blockIdx.x & 7u, seq = blockIdx.x >> 3;
-    const int k = a.k_begin + (int)(seq / (unsigned)a.seg_blocks);
+    // A segment space is one plane, or -- small grids, whose planes would leave a fifth of the lanes
+    // of wave-aligned segments idle -- the `flat` planes of the launch taken as one run of words.
     const unsigned in_seg = (seq % (unsigned)a.seg_blocks) * blockDim.x + threadIdx.x;
-    const unsigned in_plane = xcd * (unsigned)a.seg_words + in_seg;      // word within the plane
-    const int y = (int)(in_plane / (unsigned)p4);
-    const int x4 = (int)(in_plane % (unsigned)p4) * 4;
+    const unsigned in_space = xcd * (unsigned)a.seg_words + in_seg;      // word within the segment space
+    const unsigned row = in_space / (unsigned)p4;
+    const int x4 = (int)(in_space - row * (unsigned)p4) * 4;
+    const unsigned kp = a.flat > 1 ? row / (unsigned)g.ny : 0u;
+    const int y = (int)(row - kp * (unsigned)g.ny);
+    const int k = a.k_begin + (int)(seq / (unsigned)a.seg_blocks) * a.flat + (int)kp;
+    const long long in_plane = (long long)in_space - (long long)kp * a.plane_words;
     const long long t = (long long)k * a.plane_words + in_plane;
-    const bool act = in_seg < (unsigned)a.seg_words && in_plane < (unsigned)a.plane_words && k < a.k_end && x4 < g.nx;
+    const bool act = in_seg < (unsigned)a.seg_words && (long long)in_space < (long long)a.flat * a.plane_words &&
+                     k < a.k_end && x4 < g.nx;
     const int z = g.gz0 + k;
     const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
     const size_t o = act ? (size_t)(k + 1) * ps + (size_t)y * rs + x4 : ps;
@@ -346,7 +352,8 @@ template <bool ONE, int W, bool MUR> __global__ __launch_bounds__(256, W) void f
 void launch_sweep3d(const Fused3D &a, void *stream)
 {
     if (a.k_end <= a.k_begin) return;
-    const dim3 grid((unsigned)a.seg_blocks * 8u * (unsigned)(a.k_end - a.k_begin) + (a.ring ? 1u : 0u));
+    const unsigned spaces = (unsigned)((a.k_end - a.k_begin + a.flat - 1) / a.flat);
+    const dim3 grid((unsigned)a.seg_blocks * 8u * spaces + (a.ring ? 1u : 0u));
     const dim3 block((unsigned)a.block);
     static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 3;
 #define GO(W, MUR)                                                                                     \

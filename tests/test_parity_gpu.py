@@ -46,7 +46,8 @@ def test_3d_vacuum_fields_match_oracle(oracle, kernel):
 @pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, "fused, Mur launch", B.KERNEL_SPLIT])
 @pytest.mark.parametrize("dims,ecoef", [((23, 19, 17), REF), ((23, 19, 17), CON), ((64, 5, 9), CON),
                                          ((3, 3, 3), REF), ((130, 7, 4), REF), ((265, 12, 6), CON),
-                                         ((300, 9, 5), CON), ((4, 4, 4), REF), ((5, 4, 6), CON)])
+                                         ((300, 9, 5), CON), ((4, 4, 4), REF), ((5, 4, 6), CON),
+                                         ((128, 32, 5), CON)])    # planes that fill their XCD segments
 def test_3d_random_state_debye_and_mur(oracle, monkeypatch, dims, ecoef, kernel):
     """Random fields, random tissue map, non-uniform rp planes, two sources: every
     term of every kernel (all 12 Mur cases, the ey high-x quirk) is exercised.  Grids of this size

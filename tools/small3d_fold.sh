@@ -8,7 +8,7 @@ d=json.load(open("gpurun_out/sm.json"))
 print("%-60s %9.2f us/step %8.1f Gcell/s"%(sys.argv[1], d["ms_per_step"]*1e3, d["value"]/1e3), flush=True)
 PY
 }
-for n in "64 64 64" "100 100 100" "128 128 128"; do set -- $n
+for n in "50 50 50" "100 100 100" "128 128 128" "265 490 8" "90 110 130"; do set -- $n
   for f in 0 1; do
     export FDTD_3D_FOLD_MUR=$f
     run --nx $1 --ny $2 --nz $3 --steps 1000 --warmup 50 --kernel fused || exit 1

@@ -1088,14 +1088,14 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     c->kernel = opt->kernel;
     c->auto_kernel = c->kernel == FDTD_KERNEL_AUTO;
     if (c->kernel == FDTD_KERNEL_AUTO) {
-        // 2-D: the row-marching multi-step sweep from 7 M cells up; below, a pass of it is bound by
+        // 2-D: the row-marching multi-step sweep from 9 M cells up; below, a pass of it is bound by
         // the latency of its march, not by bandwidth, and the tiled multi-step sweep is faster
-        // (2048^2: 311 against 205 Gcell-updates/s, 1024^2: 211 against 81; 3072^2: 315 against 319,
-        // 4096^2: 349 against 347, 8192^2: 378 against 645).
+        // (2048^2: 311 against 205 Gcell-updates/s, 1024^2: 211 against 81; 2896^2: 329 against 290; 3072^2:
+        // 315 against 316, 4096^2: 349 against 378, 8192^2: 378 against 647).
         // Decided from the extents of the WHOLE grid, so that every slab of it takes the same kernel.
         // Smaller 2-D grids are bound by launch and memory latency: the tiled sweep advances them
         // several steps per launch out of registers and LDS.
-        c->kernel = !c->is2d() ? FDTD_KERNEL_FUSED : (double)p->nx * (double)p->ny >= 7e6 ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_TILE;
+        c->kernel = !c->is2d() ? FDTD_KERNEL_FUSED : (double)p->nx * (double)p->ny >= 9e6 ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_TILE;
     }
     if (c->kernel == FDTD_KERNEL_TILE) {
         // the storage, the schedule and the halo protocol of the multi-step mode, another sweep kernel
@@ -1111,10 +1111,11 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             set_error("FDTD_KERNEL_MULTISTEP and FDTD_KERNEL_TILE exist for the 2-D TMz mode only");
             return -3;
         }
-        // (4096^2: 270 Gcell-updates/s at 6 steps per pass, 252 at 8; 8192^2: 422 against 448);
+        // (3072^2: 316 Gcell-updates/s at 6 steps per pass, 294 at 8; 3584^2: 326 against 305; 4096^2: 361
+        // against 381);
         // from the extents of the whole grid: every slab must advance the same number of steps
         // between two halo exchanges
-        const bool mid = (double)p->nx * (double)p->ny < 48e6;
+        const bool mid = (double)p->nx * (double)p->ny < 14e6;
         c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : (mid && !c->tile) ? 6 : kDefaultStepsPerPass;
         c->spp_fixed = opt->steps_per_pass > 0 || (opt->slab_count > 0 && opt->slab_count != p->ny);
         if (c->tb_steps < (c->tile ? 1 : 2) || c->tb_steps > kMaxStepsPerPass) {
@@ -1134,12 +1135,19 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->tb_rows == 0) {
         // Rows per wave: tall bands keep the rows a wave re-marches (2K - 1 per band) cheap, short ones give
-        // the launch enough waves to keep 2048 of them in flight until its end.  Measured optimum: about
-        // 4800 waves per launch, at most 176 rows (16384^2: 176 rows 779 Gcell-updates/s, 96 rows 728;
-        // 8480x15680: 96 and 112 rows 612, 64 and 128 rows 590; 12288^2: 128 rows 706, 160 rows 677;
-        // 8192^2: 64 rows 613, 32 rows 520).
+        // the launch enough waves to keep 2048 of them in flight until its end.  Measured optimum on large
+        // grids: about 4800 waves per launch, at most 176 rows (16384^2: 176 rows 779 Gcell-updates/s, 96
+        // rows 728; 8480x15680: 96 and 112 rows 612, 64 and 128 rows 590; 12288^2: 128 rows 706, 160 rows
+        // 677; 10240^2: 112 rows 673, 96 rows 654).  Below 400 000 band-rows x strips the optimum is sharp
+        // and sits higher than that (4096^2: 32 rows 381, 16 rows 330, 48 rows 291; 5120^2: 32 rows 495,
+        // 24 rows 422, 48 rows 413; 6144^2: 48 rows 537, 32 rows 472, 64 rows 451; 4096x8192 and 8192x4096:
+        // 48 rows 515 / 536, 32 rows 464 / 496; 7168^2: 56 rows 601; 8192^2: 64 rows 649, 48 rows 590;
+        // 8704^2: 80 rows 626, 64 rows 604; 9216^2: 72 rows 651, 80 rows 643, 64 rows 628).
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
-        const long want = ((long)c->sn * strips / 4800 + 8) / 16 * 16;
+        const long work = (long)c->sn * strips;
+        long want = (work / 4800 + 8) / 16 * 16;
+        if (work < 400000)
+            want = work < 60000 ? 16 : work < 130000 ? 32 : work < 190000 ? 48 : work < 250000 ? 56 : work < 300000 ? 64 : 80;
         c->tb_rows = (int)std::min(176L, std::max(16L, want));
         if ((double)c->nx * c->sn < 6e6) c->tb_rows = (int)std::max(4L, std::min((long)c->tb_rows, (long)c->sn * strips / 2048));
     }

@@ -62,7 +62,7 @@ enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
  * steps out of registers and LDS and writes the Mur faces and the probe rows
  * itself: ONE launch per pass, for grids that are bound by launch and memory
  * latency instead of bandwidth.  steps_per_pass 1 .. 8.
- * AUTO: 2-D grids of 7 M cells or more MULTISTEP, smaller ones TILE (extents of
+ * AUTO: 2-D grids of 9 M cells or more MULTISTEP, smaller ones TILE (extents of
  * the WHOLE grid, so every slab of it decides alike), 3-D FUSED; a whole grid
  * whose MULTISTEP arrays do not fit into device memory falls back to FUSED, a
  * slab reports the error. */

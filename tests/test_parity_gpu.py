@@ -583,7 +583,7 @@ def test_2d_tiled_sweep_4096_whole_field_and_auto_choice(oracle):
     assert np.abs(want[:, 1:3, 3]).max() > 0          # the wave reached the face probes
     assert np.array_equal(s.read_probes(0, steps).view(np.uint32), want.view(np.uint32))
     s.close()
-    # FDTD_KERNEL_AUTO: the tiled sweep below 7 M cells, the row-marching one from there on
+    # FDTD_KERNEL_AUTO: the tiled sweep below 9 M cells, the row-marching one from there on
     for dims, name in (((2048, 2048), "fdtd2d_tile"), ((3072, 3072), "fdtd2d_sweep_tb")):
         auto = fdtd_amd.Solver(fdtd_amd.make_params(*dims, 1, [(100, 100, 0)]), ecoef=CON)
         assert auto.sweep_kernel_name == name, dims

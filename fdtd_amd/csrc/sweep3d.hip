@@ -52,7 +52,8 @@ __device__ __forceinline__ f4 shift_right(f4 v, int lane, float edge)
     return r;
 }
 
-template <bool ONE, int W, bool MUR> __global__ __launch_bounds__(256, W) void fdtd3d_sweep(const Fused3D a)
+// FLAT: the segment space is all planes of the launch (small grids), not one plane.
+template <bool ONE, int W, bool MUR, bool FLAT> __global__ __launch_bounds__(256, W) void fdtd3d_sweep(const Fused3D a)
 {
     const Grid3D &g = a.g;
     const int lane = threadIdx.x & 63;
@@ -85,12 +86,13 @@ template <bool ONE, int W, bool MUR> __global__ __launch_bounds__(256, W) void f
     const unsigned in_space = xcd * (unsigned)a.seg_words + in_seg;      // word within the segment space
     const unsigned row = in_space / (unsigned)p4;
     const int x4 = (int)(in_space - row * (unsigned)p4) * 4;
-    const unsigned kp = a.flat > 1 ? row / (unsigned)g.ny : 0u;
+    const unsigned kp = FLAT ? row / (unsigned)g.ny : 0u;
     const int y = (int)(row - kp * (unsigned)g.ny);
-    const int k = a.k_begin + (int)(seq / (unsigned)a.seg_blocks) * a.flat + (int)kp;
+    const int k = a.k_begin + (FLAT ? (int)kp : (int)(seq / (unsigned)a.seg_blocks));
     const long long in_plane = (long long)in_space - (long long)kp * a.plane_words;
     const long long t = (long long)k * a.plane_words + in_plane;
-    const bool act = in_seg < (unsigned)a.seg_words && (long long)in_space < (long long)a.flat * a.plane_words &&
+    const bool act = in_seg < (unsigned)a.seg_words &&
+                     (FLAT ? (long long)in_space < (long long)a.flat * a.plane_words : in_space < (unsigned)a.plane_words) &&
                      k < a.k_end && x4 < g.nx;
     const int z = g.gz0 + k;
     const size_t rs = (size_t)g.pitch, ps = (size_t)g.ny * g.pitch;
@@ -356,20 +358,25 @@ void launch_sweep3d(const Fused3D &a, void *stream)
     const dim3 grid((unsigned)a.seg_blocks * 8u * spaces + (a.ring ? 1u : 0u));
     const dim3 block((unsigned)a.block);
     static const int waves = std::getenv("FDTD_SWEEP3D_WAVES") ? std::atoi(std::getenv("FDTD_SWEEP3D_WAVES")) : 3;
-#define GO(W, MUR)                                                                                     \
-    do {                                                                                               \
-        if (a.ntab == 1)                                                                               \
-            hipLaunchKernelGGL((fdtd3d_sweep<true, W, MUR>), grid, block, 0, (hipStream_t)stream, a);  \
-        else                                                                                           \
-            hipLaunchKernelGGL((fdtd3d_sweep<false, W, MUR>), grid, block, 0, (hipStream_t)stream, a); \
+#define GO(W, MUR, FLAT)                                                                                     \
+    do {                                                                                                     \
+        if (a.ntab == 1)                                                                                     \
+            hipLaunchKernelGGL((fdtd3d_sweep<true, W, MUR, FLAT>), grid, block, 0, (hipStream_t)stream, a);  \
+        else                                                                                                 \
+            hipLaunchKernelGGL((fdtd3d_sweep<false, W, MUR, FLAT>), grid, block, 0, (hipStream_t)stream, a); \
     } while (0)
     // the Mur cases keep the neighbour words of the H update alive to the end: two waves per SIMD
-    if (a.mur)
-        GO(2, true);
+    const bool flat = a.flat > 1;
+    if (a.mur && flat)
+        GO(2, true, true);
+    else if (a.mur)
+        GO(2, true, false);
+    else if (flat)
+        GO(3, false, true);
     else if (waves == 2)
-        GO(2, false);
+        GO(2, false, false);
     else
-        GO(3, false);
+        GO(3, false, false);
 #undef GO
 }
 

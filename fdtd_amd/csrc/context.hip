@@ -1569,10 +1569,11 @@ int fdtd_step(fdtd_ctx *c, int nsteps)
 int fdtd_steps_per_pass(const fdtd_ctx *c)
 {
     if (c->kernel != FDTD_KERNEL_MULTISTEP) return 1;
-    // Several materials on a whole grid: 7 steps per pass with four waves per workgroup beat 8 with
-    // three.  Slabs keep the number they were created with: every rank must advance the same
-    // number of steps between two exchanges whatever materials it holds.
-    if (c->spp_fixed || c->tile || c->ntab_eff() == 1) return c->tb_steps;
+    // Several materials on a whole grid: up to kWideTableRowsK8 table rows fit beside the parked rows
+    // of 8 steps per pass; beyond, 7 steps per pass with four waves per workgroup beat 8 with three.
+    // Slabs keep the number they were created with: every rank must advance the same number of steps
+    // between two exchanges whatever materials it holds.
+    if (c->spp_fixed || c->tile || c->ntab_eff() <= kWideTableRowsK8) return c->tb_steps;
     return std::min(c->tb_steps, kFastStepsPerPassTable);
 }
 

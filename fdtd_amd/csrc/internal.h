@@ -34,6 +34,7 @@ struct alignas(16) MatEntry {
 // Rows of the wide coefficient table a workgroup of the multi-step sweep can hold in LDS next to
 // its parked rows (48 bytes each); grids whose highest material code is below take it.
 constexpr int kWideTableRows = 160;
+constexpr int kWideTableRowsK8 = 84; // at 8 steps per pass the LDS has 4 KB left for the table: 84 rows of 48 bytes
 
 struct MaterialRow {
     float sigma, eps_s, eps_inf, tau_d;

@@ -61,12 +61,15 @@ template <bool INX, bool INY> struct LoopMode {
     static constexpr bool inx = INX, iny = INY;
 };
 
-// Waves per workgroup: four, except for the table variant at K = 8, whose 20 KB of parked rows per
-// wave plus the 4 KB table allow three (two workgroups per CU either way).
+// Waves per workgroup: four, except for the 16-byte-row table variant at K = 8, whose 20 KB of parked
+// rows per wave plus the 4 KB table allow three (two workgroups per CU either way).  The 48-byte-row
+// variant holds at most kWideTableRowsK8 rows there and keeps one more hy row in registers, which
+// leaves room for four waves: 2 x (4 x 19 KB + 4 KB) = 160 KB.
 #ifndef FDTD_TB8_TABLE_WAVES
 #define FDTD_TB8_TABLE_WAVES 3
 #endif
-template <int K, bool ONE> constexpr int tb_waves() { return (!ONE && K >= 8) ? FDTD_TB8_TABLE_WAVES : 4; }
+template <int K, bool ONE, bool WIDE> constexpr int tb_waves() { return (!ONE && !WIDE && K >= 8) ? FDTD_TB8_TABLE_WAVES : 4; }
+template <int K> constexpr int wide_rows() { return K >= 8 ? kWideTableRowsK8 : kWideTableRows; }
 
 // At least two waves per SIMD (the register allocator otherwise settles for one at some K).
 // PLAIN: loads without the nontemporal hint (the default).
@@ -74,18 +77,18 @@ template <int K, bool ONE> constexpr int tb_waves() { return (!ONE && K >= 8) ? 
 // which the 16-byte rows make every cell rebuild from dt and tau (7 fp64 instructions per cell
 // and stage); at most kWideTableRows material codes.
 template <int K, bool ONE, bool PLAIN, bool WIDE>
-__global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 ? 1 : 2)) void fdtd2d_sweep_tb(const SweepTB a)
+__global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_sweep_tb(const SweepTB a)
 {
-    constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords, WPB = tb_waves<K, ONE>();
+    constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords, WPB = tb_waves<K, ONE, WIDE>();
     // Grids with several materials: the coefficient table sits in LDS, where a lookup per cell and
     // stage costs a fraction of a cached global load.
     __shared__ MatEntry tab[(ONE || WIDE) ? 1 : FDTD_MAX_CODES];
-    __shared__ MatCoef tabw[(!ONE && WIDE) ? kWideTableRows : 1];
+    __shared__ MatCoef tabw[(!ONE && WIDE) ? wide_rows<K>() : 1];
     if (!ONE) {
         if (WIDE) {
             const f4 *src = (const f4 *)a.table_wide;
             f4 *dst = (f4 *)tabw;
-            for (int i = threadIdx.x; i < kWideTableRows * 3; i += WPB * 64) dst[i] = src[i];
+            for (int i = threadIdx.x; i < wide_rows<K>() * 3; i += WPB * 64) dst[i] = src[i];
         } else {
             for (int i = threadIdx.x; i < FDTD_MAX_CODES; i += WPB * 64) tab[i] = a.table[i];
         }
@@ -180,11 +183,14 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
     // stage s works on next; every lane reads and writes its own 16 bytes, no other wave touches
     // them: no barriers.
     // (K = 8: 21 slots per wave would leave room for one block per CU only; the hy of its last
-    // stage stays in registers instead.)
-    constexpr bool HY_LAST_IN_REGS = K >= 8;
-    __shared__ f4 parked[WPB][K > 1 ? 3 * (K - 1) - (HY_LAST_IN_REGS ? 1 : 0) : 1][64];
+    // stage -- with the 48-byte table rows, of its last two stages -- stays in registers instead.)
+    // Slots of a wave: {ez, dz} of stage 2, 3, ... K first, then the hy slots of the stages that park it.
+    constexpr int HYR = K >= 8 ? ((!ONE && WIDE) ? 2 : 1) : 0;
+    __shared__ f4 parked[WPB][K > 1 ? 3 * (K - 1) - HYR : 1][64];
     f4(*park_w)[64] = parked[threadIdx.x >> 6];
-    auto park = [&](int stage_index, int which) -> f4 & { return park_w[3 * stage_index + which][lane]; };
+    auto park = [&](int stage_index, int which) -> f4 & {
+        return park_w[which < 2 ? 2 * stage_index + which : 2 * (K - 1) + stage_index][lane];
+    };
 
     // One stage: level s-1 of row r (with ez, dz of level s-2, ez of row r + 1, hx of level s of
     // row r - 1) -> level s of row r.
@@ -337,7 +343,10 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
     // D update of stage s needs; the last stage keeps that row's hx in hx_top.
     Level c[K + 1];
     f4 hx_top = zero;
-    f4 hy_last = zero, hy_last_new = zero; // HY_LAST_IN_REGS: hy of level K-1 for stage K, this and the next iteration
+    // hy of level s-1 for the last HYR stages (index K - s), this and the next iteration
+    f4 hy_reg[HYR > 0 ? HYR : 1], hy_reg_new[HYR > 0 ? HYR : 1];
+#pragma unroll
+    for (int i = 0; i < (HYR > 0 ? HYR : 1); ++i) hy_reg[i] = hy_reg_new[i] = zero;
 #pragma unroll
     for (int s = 0; s <= K; ++s) {
         c[s].ez = c[s].hx = c[s].dz = zero;
@@ -372,9 +381,9 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
                 dzp = park(s - 2, 1);
                 park(s - 2, 0) = pend_e;
                 park(s - 2, 1) = pend_d;
-                if (HY_LAST_IN_REGS && s == K) {
-                    hyin = hy_last;
-                    hy_last_new = pend_h;
+                if (s > K - HYR) {
+                    hyin = hy_reg[s > K - HYR ? K - s : 0];
+                    hy_reg_new[s > K - HYR ? K - s : 0] = pend_h;
                 } else {
                     hyin = park(s - 2, 2);
                     park(s - 2, 2) = pend_h;
@@ -397,7 +406,7 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
                 }
                 // c[s + 1] now holds the final level s of row r - 1
                 if (!INY && prbmask && own && r - 1 >= y0 && r - 1 < y1)
-                    record(c[s + 1], (HY_LAST_IN_REGS && s + 1 == K) ? hy_last : park(s - 1, 2), r - 1, a.slot[s]);
+                    record(c[s + 1], (s + 1 > K - HYR) ? hy_reg[s + 1 > K - HYR ? K - (s + 1) : 0] : park(s - 1, 2), r - 1, a.slot[s]);
                 keep[s + 1].ez = o.ez;
                 keep[s + 1].hx = o.hx;
                 keep[s + 1].dz = o.dz;
@@ -421,7 +430,8 @@ __global__ __launch_bounds__((tb_waves<K, ONE>() * 64), (tb_waves<K, ONE>() > 4 
         }
 #pragma unroll
         for (int s = 2; s <= K; ++s) c[s] = keep[s];
-        hy_last = hy_last_new;
+#pragma unroll
+        for (int i = 0; i < (HYR > 0 ? HYR : 1); ++i) hy_reg[i] = hy_reg_new[i];
         ezc = cur.ezu;
         cur = nxt;
     }
@@ -445,7 +455,9 @@ template <int K> int launch_k(const SweepTB &a, hipStream_t stream)
     const long bands = a.big_bands + tail;
     if (bands <= 0) return 0;
     const bool one = a.ntab == 1;
-    const long wpb = one ? tb_waves<K, true>() : tb_waves<K, false>();
+    static const bool narrow = std::getenv("FDTD_TB_NARROW_TABLE") && std::atoi(std::getenv("FDTD_TB_NARROW_TABLE"));
+    const bool wide = !one && a.ntab <= wide_rows<K>() && !narrow;
+    const long wpb = one ? tb_waves<K, true, false>() : wide ? tb_waves<K, false, true>() : tb_waves<K, false, false>();
     long blocks;
     if (a.map == 0)
         blocks = (bands * a.strips + wpb - 1) / wpb;
@@ -456,13 +468,12 @@ template <int K> int launch_k(const SweepTB &a, hipStream_t stream)
     // second of them (16384^2, K = 8: 3.32 ms per pass against 3.42 with the hint).  The hinted
     // form is kept for K = 8 on a single material as a tuning reference (FDTD_TB_PLAIN_LOADS=0).
     static const bool hinted = std::getenv("FDTD_TB_PLAIN_LOADS") && !std::atoi(std::getenv("FDTD_TB_PLAIN_LOADS"));
-    static const bool narrow = std::getenv("FDTD_TB_NARROW_TABLE") && std::atoi(std::getenv("FDTD_TB_NARROW_TABLE"));
     if (one) {
         if (K == 8 && hinted)
             hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, K != 8, false>), grid, block, 0, stream, a);
         else
             hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, true, false>), grid, block, 0, stream, a);
-    } else if (a.ntab <= kWideTableRows && !narrow) {
+    } else if (wide) {
         hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, true>), grid, block, 0, stream, a);
     } else {
         hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, false>), grid, block, 0, stream, a);

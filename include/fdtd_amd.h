@@ -76,8 +76,8 @@ typedef struct fdtd_options {
     int32_t slab_begin;  /* first global row of the slab axis held here (y in 2-D, z in 3-D) */
     int32_t slab_count;  /* rows held; 0 = the whole grid */
     int32_t chunk_rows;  /* rows marched by one workgroup of the fused sweep; 0 = default */
-    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (8, 6 below 48 M cells; a whole grid drops to
-                             * 7 once several materials are on it, a slab or an explicit value never changes) */
+    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (8, 6 below 14 M cells; a whole grid drops to
+                             * 7 once it holds material codes above 83, a slab or an explicit value never changes) */
     int32_t reserved[8];
 } fdtd_options;
 

@@ -468,6 +468,31 @@ def test_grid_of_one_non_default_material(oracle, dims, kernel):
     assert util.run_and_compare(s, o, 30, 15, "two materials") == 0
 
 
+@pytest.mark.parametrize("dims,spp", [((4096, 3600), 0), ((530, 140), 8), ((530, 140), 5)])
+def test_2d_material_codes_beyond_the_wide_table(oracle, dims, spp):
+    """Material codes above 83: their table rows (48 bytes each) do not fit beside the parked rows of 8
+    steps per pass.  Left to itself the library then takes 7 steps per pass; asked for 8 it takes the
+    table of 16-byte rows with three waves per workgroup.  Same numbers either way."""
+    nx, ny = dims          # (the library chooses 8 steps per pass from 14 M cells up)
+    kernel = B.KERNEL_MULTISTEP if spp == 0 else (B.KERNEL_MULTISTEP, spp)
+    s, o = util.pair(oracle, (nx, ny, 1), [(nx // 2, ny // 2, 0), (3, 3, 0)], CON, kernel=kernel, sigma=0.2, eps_s=9.0,
+                     eps_i=3.0, tau_d=2e-11)
+    rng = np.random.default_rng(99)
+    table = np.tile(np.array([0.2, 9.0, 3.0, 2e-11], dtype=np.float32), (201, 1))
+    table[:len(util.RIKEN_LIKE)] = util.RIKEN_LIKE
+    table[120] = [0.9, 40.0, 10.0, 2.5e-11]
+    table[200] = [0.05, 6.0, 2.5, 0.9e-11]
+    codes = rng.choice(np.array([0, 1, 3, 120, 200], dtype=np.uint8), size=(ny, nx))
+    assert s.steps_per_pass == (spp or 8)
+    util.set_materials(s, o, codes, table)
+    assert s.steps_per_pass == (spp or 7)
+    for face in (0, 1, 3, 4):          # x0, y0, xEnd, yEnd
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    assert util.run_and_compare(s, o, 45 if spp else 22, 15 if spp else 11, "codes up to 200") == 0
+
+
 # ------------------------------------------------------------------ results path
 
 @pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS5, TL1, TL3, TL8])
@@ -625,9 +650,9 @@ def test_2d_largest_grid_65536_window_and_causality(oracle):
 def test_2d_tissue_map_8480x15680_whole_field(oracle):
     """The dispersive workload at its full size: v1_00800.pgm upsampled x32 (8480 x 15680, 133 M
     cells, 8 tissues), mat_specs_riken, Mur with the default rp, a source in the air beside the
-    body.  32 steps (4 passes of 7 + one of 4) against the oracle on the whole grid: every
+    body.  36 steps (4 passes of 8 + one of 4) against the oracle on the whole grid: every
     cell of every field bit for bit."""
-    u, steps = 32, 32
+    u, steps = 32, 36
     nx, ny = 265 * u, 490 * u
     src = [(40 * u, 245 * u, 0)]
     s = fdtd_amd.Solver(fdtd_amd.make_params(nx, ny, 1, src), ecoef=CON, kernel=B.KERNEL_MULTISTEP)
@@ -638,7 +663,7 @@ def test_2d_tissue_map_8480x15680_whole_field(oracle):
     table, _ = B.read_material_specs(specs)
     codes = B.read_pgm_codes(os.path.join(pgm, "v1_00800.pgm"), 265, 490)
     o.set_materials(np.repeat(np.repeat(codes, u, axis=0), u, axis=1)[None], table)
-    assert s.steps_per_pass == 7          # 8 in vacuum; the material table takes part of the LDS
+    assert s.steps_per_pass == 8          # the highest code of the map is 51: its table rows fit beside 8 steps
     s.step(steps)
     o.step(steps, threads=16)
     for fid in (B.HX, B.HY, B.DZ, B.EZ):

@@ -2,7 +2,7 @@
 """Benchmark of the FDTD field-update path on MI355X.
 
 One "step" is one full time step (H, D, source, E, Mur) of one slab.  At
---gpus 1 the workload is BASELINE.json's configs[1]: a 16384 x 16384 2-D TMz
+--gpus 1 the workload is the headline configuration: a 16384 x 16384 2-D TMz
 grid, vacuum, one point source at the centre.  At --gpus N every rank holds a
 16384 x 16384 slab of a 16384 x (16384*N) grid (weak scaling) and exchanges halo
 rows with each neighbour over RCCL on a second stream, beside the sweep of the

@@ -1,4 +1,4 @@
-# The measurements DESIGN.md quotes, one line each (run through gpurun from the repo root).
+# The headline measurements, one line each (run through gpurun from the repo root).
 cd $GRAFT_REPO_ROOT
 run() {
   timeout -k 10 400 python bench.py --no-cpu-baseline "$@" > gpurun_out/sm.json 2>gpurun_out/sm.err || { tail -3 gpurun_out/sm.err; return 1; }

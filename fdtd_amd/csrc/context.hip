@@ -1116,7 +1116,10 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         // from the extents of the whole grid: every slab must advance the same number of steps
         // between two halo exchanges
         const bool mid = (double)p->nx * (double)p->ny < 14e6;
-        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : (mid && !c->tile) ? 6 : kDefaultStepsPerPass;
+        // (the tiled sweep from 3 M cells up, where its tiles take several rounds: 2048^2 329 at 6 steps per
+        // launch, 312 at 8; 2896^2 347 against 333; 1024^2 205 against 210)
+        const bool tile6 = c->tile && (double)p->nx * (double)p->ny >= 3e6;
+        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : ((mid && !c->tile) || tile6) ? 6 : kDefaultStepsPerPass;
         c->spp_fixed = opt->steps_per_pass > 0 || (opt->slab_count > 0 && opt->slab_count != p->ny);
         if (c->tb_steps < (c->tile ? 1 : 2) || c->tb_steps > kMaxStepsPerPass) {
             set_error("steps_per_pass must be 2 .. 8 (FDTD_KERNEL_TILE: 1 .. 8)");

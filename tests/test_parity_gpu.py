@@ -590,7 +590,7 @@ def test_2d_tiled_sweep_4096_whole_field_and_auto_choice(oracle):
     bit, and the probe series of every step."""
     n, steps = 4096, 100
     src = [(60, 70, 0), (2048, 2048, 0)]
-    s = fdtd_amd.Solver(fdtd_amd.make_params(n, n, 1, src), ecoef=CON, kernel=B.KERNEL_TILE)
+    s = fdtd_amd.Solver(fdtd_amd.make_params(n, n, 1, src), ecoef=CON, kernel=TL8)
     assert s.sweep_kernel_name == "fdtd2d_tile" and s.steps_per_pass == 8
     probes = [[60, 70, 0], [0, 70, 0], [61, 0, 0], [2048, 2049, 0], [4095, 4095, 0]]
     s.set_probes(probes, capacity=steps)
@@ -609,9 +609,11 @@ def test_2d_tiled_sweep_4096_whole_field_and_auto_choice(oracle):
     assert np.array_equal(s.read_probes(0, steps).view(np.uint32), want.view(np.uint32))
     s.close()
     # FDTD_KERNEL_AUTO: the tiled sweep below 9 M cells, the row-marching one from there on
-    for dims, name in (((2048, 2048), "fdtd2d_tile"), ((3072, 3072), "fdtd2d_sweep_tb")):
+    # (steps per launch: 8, from 3 M cells up 6; the row-marching sweep 6 below 14 M cells, then 8)
+    for dims, name, spp in (((1024, 1024), "fdtd2d_tile", 8), ((2048, 2048), "fdtd2d_tile", 6),
+                            ((3072, 3072), "fdtd2d_sweep_tb", 6), ((4096, 4096), "fdtd2d_sweep_tb", 8)):
         auto = fdtd_amd.Solver(fdtd_amd.make_params(*dims, 1, [(100, 100, 0)]), ecoef=CON)
-        assert auto.sweep_kernel_name == name, dims
+        assert auto.sweep_kernel_name == name and auto.steps_per_pass == spp, dims
         auto.close()
 
 

@@ -314,7 +314,7 @@ int launch_sweep2d_tile(const SweepTile &t, void *stream)
     static const int forced = std::getenv("FDTD_TILE_ROWS") ? std::atoi(std::getenv("FDTD_TILE_ROWS")) : 0;
     const long nw = (t.b.g.nx + 3) / 4, n = t.b.y_end - t.b.y_begin;
     const long tall = ((nw + 11) / 12) * ((n + (64 - 2 * t.steps) - 1) / (64 - 2 * t.steps));
-    int rows = (tall >= 256 && tall < 1024) ? 64 : 32;
+    int rows = (tall >= 256 && tall <= 1100) ? 64 : 32; // (1536^2, 1024 tall tiles: 268 against 235; 1792^2, 1444: 282 against 291)
     if (forced) rows = forced;
     switch (rows) {
     case 32: return launch_tile<16, 32, 1>(t, (hipStream_t)stream);

@@ -8,9 +8,9 @@ d=json.load(open("gpurun_out/sm.json"))
 print("%-75s %9.2f us/step %8.1f Gcell/s"%(sys.argv[1], d["ms_per_step"]*1e3, d["value"]/1e3), flush=True)
 PY
 }
-for n in 1024 2048 2896; do
-  for k in 4 6 8; do
-    for r in 32 64 642; do
+for n in ${SIZES:-1024 2048 2896}; do
+  for k in ${KS:-4 6 8}; do
+    for r in ${ROWS:-32 64 642}; do
       FDTD_TILE_ROWS=$r run --nx $n --ny $n --steps 960 --warmup 48 --kernel tile --steps-per-pass $k || exit 1
     done
   done

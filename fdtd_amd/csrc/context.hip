@@ -700,7 +700,7 @@ int step_once(fdtd_ctx *c, bool last)
                 f.seg_words = (int)(((f.flat * f.plane_words + 7) / 8 + 63) / 64 * 64);
                 // 256 threads per block, fewer where the last block of a segment would be mostly idle
                 // (100^3: segments of 384 words)
-                f.block = f.seg_words % 256 == 0 || f.seg_words >= 4096 ? 256 : f.seg_words % 128 == 0 ? 128 : 64;
+                f.block = f.seg_words % 256 == 0 || f.seg_words >= 4096 ? 256 : f.seg_words % 192 == 0 ? 192 : f.seg_words % 128 == 0 ? 128 : 64;
                 f.seg_blocks = (f.seg_words + f.block - 1) / f.block;
             };
             f.ring = nullptr;

@@ -69,6 +69,47 @@ def test_3d_random_state_debye_and_mur(oracle, monkeypatch, dims, ecoef, kernel)
     assert util.run_and_compare(s, o, 12, 3, f"{dims}") == 0
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("FDTD_TEST_3D_SEEDS", "16"))))   # more seeds for a soak run
+def test_3d_random_cases(oracle, monkeypatch, seed):
+    """Seeded random 3-D cases: extents (rows that are no multiple of four cells, planes that end inside
+    a wave or an XCD segment), tissue maps, rp planes, sources and probes anywhere, the way the steps are
+    cut into calls; with the Mur faces inside the sweep or as a launch of their own."""
+    rng = np.random.default_rng(9000 + seed)
+    nx, ny, nz = int(rng.integers(4, 70)), int(rng.integers(4, 40)), int(rng.integers(4, 30))
+    if rng.random() < 0.3:
+        monkeypatch.setenv("FDTD_3D_FOLD_MUR", "0")
+    if rng.random() < 0.3:
+        monkeypatch.setenv("FDTD_3D_FLAT", "0")
+    srcs = [(int(rng.integers(1, nx)), int(rng.integers(1, ny)), int(rng.integers(0, nz)))
+            for _ in range(int(rng.integers(1, 5)))]
+    ecoef = REF if rng.random() < 0.3 else CON
+    s, o = util.pair(oracle, (nx, ny, nz), srcs, ecoef, kernel=B.KERNEL_FUSED, sigma=0.2, eps_s=9.0, eps_i=3.0,
+                     tau_d=2e-11)
+    if rng.random() < 0.7:
+        codes = rng.integers(0, len(util.RIKEN_LIKE), size=(nz, ny, nx), dtype=np.uint8)
+        util.set_materials(s, o, codes)
+    for face in range(6):
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    util.randomize(s, o, rng, oracle)
+    probes = [[int(rng.integers(0, nx)), int(rng.integers(0, ny)), int(rng.integers(0, nz))]
+              for _ in range(int(rng.integers(1, 9)))]
+    s.set_probes(probes, capacity=64)
+    steps = [int(v) for v in rng.integers(1, 7, size=3)]
+    series = []
+    for n in steps:
+        s.step(n)
+        for _ in range(n):
+            o.step(1)
+            series.append([[o.field(f)[z, y, x] for f in range(9)] for x, y, z in probes])
+    for fid in util.fields_of(s):
+        util.assert_bits_equal(s.field(fid), np.asarray(o.field(fid)), f"seed {seed} {(nx, ny, nz)} {B.FIELD_NAMES[fid]}")
+    got = s.read_probes(0, sum(steps))
+    want = np.array(series, dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (seed, nx, ny, nz)
+
+
 def test_3d_mur_from_loaded_materials(oracle):
     dims = (12, 11, 10)
     rng = np.random.default_rng(5)

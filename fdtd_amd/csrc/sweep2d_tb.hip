@@ -271,21 +271,32 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     };
 
     // Mur on the x faces of a freshly computed row (level s), fdtd_calculations.cu:369-395.
-    auto mur_x = [&](f4 &et, const f4 &es, int r) {
+    // Its field-independent factors of row r come from the per-row arrays; they are asked for before
+    // the stage that produces the row (mur_x_factors), so that the load is back when the stage is done.
+    auto mur_x_factors = [&](int r) -> f4 {
+        const int y = g.gy0 + r;
+        f4 cf = zero;
+        if (y >= 1 && y <= g.gny - 2) {
+            if (w == 0) cf = ((const f4 *)a.cfx0)[y];
+            if (wave_xe && w == xe_w) cf = ((const f4 *)a.cfxe)[y]; // (a grid of one word: the high face wins, as below)
+        }
+        return cf;
+    };
+    auto mur_x = [&](f4 &et, const f4 &es, int r, const f4 &cf) {
         const int y = g.gy0 + r;
         const bool yok = y >= 1 && y <= g.gny - 2;
-        if (w == 0 && yok)
-            et.x = mur_face(g.dt, a.dx, a.mu0, a.eps0, a.rpx0[(size_t)y * 2], a.rpx0[(size_t)y * 2 + 1], et.y, es.y,
-                            es.x);
+        if (w == 0 && yok) {
+            const f4 c0 = (wave_xe && w == xe_w) ? ((const f4 *)a.cfx0)[y] : cf;
+            et.x = mur_apply(c0, et.y, es.y, es.x);
+        }
         if (wave_xe) {
             const float t_prev = __shfl_up(et.w, 1), s_prev = __shfl_up(es.w, 1);
             if (w == xe_w && yok) {
-                const float r_here = a.rpxe[(size_t)y * 2 + 1], r_in = a.rpxe[(size_t)y * 2];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (i == xe_c) {
                         const float t_in = i ? et[i ? i - 1 : 0] : t_prev, s_in = i ? es[i ? i - 1 : 0] : s_prev;
-                        et[i] = mur_face(g.dt, a.dx, a.mu0, a.eps0, r_here, r_in, t_in, s_in, es[i]);
+                        et[i] = mur_apply(cf, t_in, s_in, es[i]);
                     }
             }
         }
@@ -389,13 +400,15 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
                     park(s - 2, 2) = pend_h;
                 }
             }
+            f4 cfx = zero;
+            if (!INX && s < K) cfx = mur_x_factors(r);
             StageOut o = stage(mode, c[s], hyin, ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r,
                                a.jz[s - 1]);
             // the next row's loads go out once stage 1 has consumed this row's registers
             if (s == 1 && j < jhi) load(mode, nxt, j + 1);
             if (s < K) {
                 const int y = g.gy0 + r;
-                if (!INX) mur_x(o.ez, c[s].ez, r);
+                if (!INX) mur_x(o.ez, c[s].ez, r, cfx);
                 if (!INY && (y == g.gny - 1 || y == 1)) {
                     // ez of level s-1 of row r - 1 is parked in the slot of stage s + 1
                     const f4 below = park(s - 1, 0);

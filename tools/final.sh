@@ -15,7 +15,7 @@ run --steps 200 --warmup 16 --kernel fused &&
 run --steps 400 --warmup 16 --no-one-step-leg --probes 16 &&
 run --steps 400 --warmup 16 --no-one-step-leg --snapshot-every 100 --probes 16 &&
 run --steps 2000 --warmup 16 --no-one-step-leg --snapshot-every 100 --probes 16 &&
-run --tissue 32 --steps 140 --warmup 14 &&
+run --tissue 32 --steps 160 --warmup 16 &&
 run --tissue 32 --steps 100 --warmup 10 --kernel fused &&
 run --nx 65536 --ny 65536 --steps 48 --warmup 8 --no-one-step-leg &&
 run --nx 65536 --ny 4096 --steps 96 --warmup 8 --no-one-step-leg &&

@@ -282,10 +282,10 @@ int upload_rp(fdtd_ctx *c, int face)
 {
     HIPCHK(hipMemcpyAsync(c->rp[face], c->rp_host[face].data(), c->rp_n[face] * sizeof(float),
                           hipMemcpyHostToDevice, c->stream));
-    // The 3-D sweep that finishes the faces itself, and the x-face strips of the multi-step 2-D sweep
-    // (x faces only), read the field-independent factors of the Mur update, taken from the plane here,
+    // The 3-D sweep that finishes the faces itself, and the multi-step 2-D sweep (for the intermediate
+    // levels of a pass), read the field-independent factors of the Mur update, taken from the plane here,
     // instead of the plane.
-    if (c->fold_mur || (c->kernel == FDTD_KERNEL_MULTISTEP && !c->tile && face % 3 == 0)) {
+    if (c->fold_mur || (c->kernel == FDTD_KERNEL_MULTISTEP && !c->tile && face % 3 != 2)) {
         if (!c->mur_cf[face]) {
             int rc = dev_alloc(c, &c->mur_cf[face], c->rp_n[face] * 2);
             if (rc) return rc;
@@ -902,6 +902,8 @@ int pass_once(fdtd_ctx *c, int K)
     a.rpxe = c->rp[FDTD_RP_XEND];
     a.cfx0 = c->mur_cf[FDTD_RP_X0];
     a.cfxe = c->mur_cf[FDTD_RP_XEND];
+    a.cfy0 = c->mur_cf[FDTD_RP_Y0];
+    a.cfye = c->mur_cf[FDTD_RP_YEND];
     a.rpy0 = c->rp[FDTD_RP_Y0];
     a.rpye = c->rp[FDTD_RP_YEND];
     a.dx = c->p.dx;

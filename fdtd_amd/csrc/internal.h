@@ -109,6 +109,7 @@ struct SweepTB {
     float jz[kMaxStepsPerPass];           // source sample of each step of the pass
     const float *rpx0, *rpxe, *rpy0, *rpye; // Mur planes, as in Mur2D
     const float *cfx0, *cfxe;               // per global row the four field-independent factors of the x-face Mur update (MurCoefs)
+    const float *cfy0, *cfye;               // the same per column for the y faces
     float dx, dy, mu0, eps0;
     ProbeList probes;
     float *ring;                          // probe ring, nullptr = no probes

@@ -302,13 +302,13 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         }
     };
     // Mur on the y faces, fdtd_calculations.cu:401-427: `here` is the face row, `in` the row next to it.
-    auto mur_y = [&](f4 &et_here, const f4 &et_in, const f4 &es_in, const f4 &es_here, const float *rp, bool high) {
+    // (factors per column from the arrays: spelled out -- two square roots and a division per cell --
+    // the two cases of every stage made the guarded loop eight times the size of the plain one)
+    auto mur_y = [&](f4 &et_here, const f4 &et_in, const f4 &es_in, const f4 &es_here, const float *cf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (!m_hx[i]) continue;
-            const int x = x4 + i;
-            const float r_face = high ? rp[g.nx + x] : rp[x], r_next = high ? rp[x] : rp[g.nx + x];
-            et_here[i] = mur_face(g.dt, a.dy, a.mu0, a.eps0, r_face, r_next, et_in[i], es_in[i], es_here[i]);
+            et_here[i] = mur_apply(((const f4 *)cf)[x4 + i], et_in[i], es_in[i], es_here[i]);
         }
     };
 
@@ -413,9 +413,9 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
                     // ez of level s-1 of row r - 1 is parked in the slot of stage s + 1
                     const f4 below = park(s - 1, 0);
                     if (y == 1)
-                        mur_y(c[s + 1].ez, o.ez, c[s].ez, below, a.rpy0, false);
+                        mur_y(c[s + 1].ez, o.ez, c[s].ez, below, a.cfy0);
                     else
-                        mur_y(o.ez, c[s + 1].ez, below, c[s].ez, a.rpye, true);
+                        mur_y(o.ez, c[s + 1].ez, below, c[s].ez, a.cfye);
                 }
                 // c[s + 1] now holds the final level s of row r - 1
                 if (!INY && prbmask && own && r - 1 >= y0 && r - 1 < y1)

@@ -7,7 +7,7 @@ i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
            "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM"; do
   i=$((i+1))
-  timeout -s KILL 200 rocprofv3 --pmc $grp --output-format csv -d "$out/pmc_$i" -- python bench.py --steps 48 --warmup 8 --no-cpu-baseline --no-one-step-leg > "$out/bench_$i.json" 2> "$out/pmc_$i.err" || { grep -v "rocprofv3\]" "$out/pmc_$i.err" | tail -5; exit 1; }
+  timeout -s KILL 200 rocprofv3 --pmc $grp --output-format csv -d "$out/pmc_$i" -- python bench.py ${DIAG_ARGS:---steps 48 --warmup 8} --no-cpu-baseline --no-one-step-leg > "$out/bench_$i.json" 2> "$out/pmc_$i.err" || { grep -v "rocprofv3\]" "$out/pmc_$i.err" | tail -5; exit 1; }
 done
 python3 - <<'PY'
 import csv, glob

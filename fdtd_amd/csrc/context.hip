@@ -1146,7 +1146,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         // the launch enough waves to keep 2048 of them in flight until its end.  Measured optimum on large
         // grids: about 4800 waves per launch, at most 176 rows (16384^2: 176 rows 779 Gcell-updates/s, 96
         // rows 728; 8480x15680: 96 and 112 rows 612, 64 and 128 rows 590; 12288^2: 128 rows 706, 160 rows
-        // 677; 10240^2: 112 rows 673, 96 rows 654).  Below 400 000 band-rows x strips the optimum is sharp
+        // 677; 10240^2: 112 rows 694, 96 rows 676).  Below 500 000 band-rows x strips the optimum is sharp
         // and sits higher than that (4096^2: 32 rows 381, 16 rows 330, 48 rows 291; 5120^2: 32 rows 495,
         // 24 rows 422, 48 rows 413; 6144^2: 48 rows 537, 32 rows 472, 64 rows 451; 4096x8192 and 8192x4096:
         // 48 rows 515 / 536, 32 rows 464 / 496; 7168^2: 56 rows 601; 8192^2: 64 rows 649, 48 rows 590;
@@ -1154,8 +1154,8 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
         const long work = (long)c->sn * strips;
         long want = (work / 4800 + 8) / 16 * 16;
-        if (work < 400000)
-            want = work < 60000 ? 16 : work < 130000 ? 32 : work < 190000 ? 48 : work < 250000 ? 56 : work < 300000 ? 64 : 80;
+        if (work < 500000)
+            want = work < 60000 ? 16 : work < 130000 ? 32 : work < 190000 ? 48 : work < 250000 ? 56 : work < 300000 ? 64 : work < 400000 ? 80 : 112;
         c->tb_rows = (int)std::min(176L, std::max(16L, want));
         if ((double)c->nx * c->sn < 6e6) c->tb_rows = (int)std::max(4L, std::min((long)c->tb_rows, (long)c->sn * strips / 2048));
     }

@@ -534,6 +534,24 @@ def test_2d_material_codes_beyond_the_wide_table(oracle, dims, spp):
     assert util.run_and_compare(s, o, 45 if spp else 22, 15 if spp else 11, "codes up to 200") == 0
 
 
+@pytest.mark.parametrize("dims,kernel", [((530, 140, 1), MS8), ((530, 140, 1), TL8), ((530, 140, 1), B.KERNEL_FUSED),
+                                         ((40, 30, 20), B.KERNEL_FUSED), ((40, 30, 20), B.KERNEL_SPLIT)])
+def test_rp_planes_replaced_between_steps(oracle, dims, kernel):
+    """fdtd_set_rp in the middle of a run: whatever a kernel keeps derived from the planes (the
+    field-independent Mur factors) follows."""
+    nx, ny, nz = dims
+    rng = np.random.default_rng(77)
+    s, o = util.pair(oracle, dims, [(nx // 2, ny // 2, nz // 2), (2, 2, 0 if nz == 1 else 1)], CON, kernel=kernel)
+    util.randomize(s, o, rng, oracle)
+    faces = (0, 1, 3, 4) if nz == 1 else range(6)
+    for round_ in range(3):
+        for face in faces:
+            rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+            s.set_rp(face, rp)
+            o.set_rp(face, rp)
+        assert util.run_and_compare(s, o, 19, 19, f"rp set {round_}") == 0
+
+
 # ------------------------------------------------------------------ results path
 
 @pytest.mark.parametrize("kernel", [B.KERNEL_FUSED, MS2, MS5, TL1, TL3, TL8])

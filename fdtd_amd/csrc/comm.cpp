@@ -107,6 +107,10 @@ struct LocalGroup {
     std::condition_variable cv;
     std::vector<std::deque<LocalMsg>> box; // [src * world + dst]: sends posted, not yet received
     std::vector<int> ack;                  // [src * world + dst]: messages of src that dst has copied out
+    // Set by the first exchange that fails on any rank (time limit, size mismatch, HIP error): posted
+    // messages and acknowledgements are then out of step, so every later exchange of the group fails
+    // too instead of pairing a stale message with a new receive.
+    bool failed = false;
 };
 
 struct LocalOp {
@@ -141,12 +145,33 @@ int hipcheck(hipError_t e, const char *what)
     return -10;
 }
 
+int local_run_ops(Comm *c, const std::vector<LocalOp> &ops);
+
 int local_run(Comm *c)
 {
     LocalGroup *g = c->local;
-    const int w = g->world, r = c->rank;
     std::vector<LocalOp> ops;
     ops.swap(c->ops);
+    {
+        std::lock_guard<std::mutex> lk(g->m);
+        if (g->failed) {
+            set_error("in-process halo exchange: an earlier exchange of this group failed; the group is unusable");
+            return -23;
+        }
+    }
+    const int rc = local_run_ops(c, ops);
+    if (rc) {
+        std::lock_guard<std::mutex> lk(g->m);
+        g->failed = true;
+        g->cv.notify_all();
+    }
+    return rc;
+}
+
+int local_run_ops(Comm *c, const std::vector<LocalOp> &ops)
+{
+    LocalGroup *g = c->local;
+    const int w = g->world, r = c->rank;
     // 1. the data to send is final once the stream has drained; post every send (never blocks on a peer)
     hipStream_t drained = nullptr;
     bool any = false;
@@ -168,8 +193,10 @@ int local_run(Comm *c)
         {
             std::unique_lock<std::mutex> lk(g->m);
             auto &q = g->box[(size_t)op.peer * w + r];
-            if (!g->cv.wait_for(lk, std::chrono::seconds(local_timeout()), [&] { return !q.empty(); })) {
-                set_error("in-process halo exchange: the neighbour rank did not send within the time limit");
+            if (!g->cv.wait_for(lk, std::chrono::seconds(local_timeout()), [&] { return !q.empty() || g->failed; }) ||
+                g->failed) {
+                set_error(g->failed ? "in-process halo exchange: the exchange failed on another rank"
+                                    : "in-process halo exchange: the neighbour rank did not send within the time limit");
                 return -23;
             }
             msg = q.front();
@@ -193,8 +220,9 @@ int local_run(Comm *c)
         if (!op.send) continue;
         std::unique_lock<std::mutex> lk(g->m);
         int &n = g->ack[(size_t)r * w + op.peer];
-        if (!g->cv.wait_for(lk, std::chrono::seconds(local_timeout()), [&] { return n > 0; })) {
-            set_error("in-process halo exchange: the neighbour rank did not receive within the time limit");
+        if (!g->cv.wait_for(lk, std::chrono::seconds(local_timeout()), [&] { return n > 0 || g->failed; }) || n <= 0) {
+            set_error(g->failed ? "in-process halo exchange: the exchange failed on another rank"
+                                : "in-process halo exchange: the neighbour rank did not receive within the time limit");
             return -23;
         }
         n--;

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -46,14 +47,17 @@ constexpr size_t kScratchFloats = (size_t)1 << 20;
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) float scratch[kScratchFloats];
 float *g_scratch[kMaxDevices] = {};
+std::mutex g_scratch_mutex; // contexts may be created from several host threads
 
-// Once per device, with that device current.
+// Once per device, with that device current.  A failure is reported by fdtd_halo_get_noalloc(),
+// the only user: every other entry point works without the array.
 int scratch_init(int device)
 {
     if (device < 0 || device >= kMaxDevices) {
         set_error("device ordinal out of range");
         return -3;
     }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (g_scratch[device]) return 0;
     float *ptr = nullptr;
     hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
@@ -63,6 +67,13 @@ int scratch_init(int device)
     }
     g_scratch[device] = ptr;
     return 0;
+}
+
+float *scratch_of(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch[device];
 }
 }
 
@@ -98,9 +109,15 @@ struct fdtd_ctx {
     MatEntry *table = nullptr;
     MatCoef *table_wide = nullptr;
     MatEntry table0 = {};
-    float *rp[6] = {};
-    size_t rp_n[6] = {};
-    float *mur_cf[6] = {}; // fold_mur: four Mur factors per face cell, kept in step with rp[]
+    // rp planes (layouts of fdtd.cu:952-1001).  Every layout is slowest in the slab axis, so what a
+    // slab reads of a plane is ONE run [rp_first, rp_first + rp_n) of the plane's rp_gn entries: the
+    // context holds that run only (a 2-D context: nothing of the z faces).  rp[] and mur_cf[] are
+    // the starts of the allocations moved back by the run's offset, so that the kernels index them
+    // with the global indices of the reference's layouts.
+    float *rp_store[6] = {}, *rp[6] = {};
+    size_t rp_first[6] = {}, rp_n[6] = {}, rp_gn[6] = {};
+    float rp_default[6] = {};
+    float *cf_store[6] = {}, *mur_cf[6] = {}; // four Mur factors per face cell, kept in step with rp[]
 
     int cur = 0;  // slot of the newest E/D level inside the current pair
     int pair = 0; // which pair of E/D arrays holds the two live levels
@@ -280,20 +297,25 @@ int upload_table(fdtd_ctx *c)
 
 int upload_rp(fdtd_ctx *c, int face)
 {
-    HIPCHK(hipMemcpyAsync(c->rp[face], c->rp_host[face].data(), c->rp_n[face] * sizeof(float),
+    if (c->rp_n[face] == 0) return 0;
+    HIPCHK(hipMemcpyAsync(c->rp_store[face], c->rp_host[face].data(), c->rp_n[face] * sizeof(float),
                           hipMemcpyHostToDevice, c->stream));
     // The 3-D sweep that finishes the faces itself, and the multi-step 2-D sweep (for the intermediate
     // levels of a pass), read the field-independent factors of the Mur update, taken from the plane here,
     // instead of the plane.
     if (c->fold_mur || (c->kernel == FDTD_KERNEL_MULTISTEP && !c->tile && face % 3 != 2)) {
-        if (!c->mur_cf[face]) {
-            int rc = dev_alloc(c, &c->mur_cf[face], c->rp_n[face] * 2);
+        if (!c->cf_store[face]) {
+            int rc = dev_alloc(c, &c->cf_store[face], c->rp_n[face] * 2);
             if (rc) return rc;
+            // (an entry of four factors per pair of rp entries: the run starts at cell rp_first / 2)
+            c->mur_cf[face] = c->cf_store[face] - c->rp_first[face] * 2;
         }
         MurCoefs m;
         m.rp = c->rp[face];
         m.cf = c->mur_cf[face];
         m.face = face;
+        m.first = (long long)(c->rp_first[face] / 2);
+        m.count = (long long)(c->rp_n[face] / 2);
         m.nx = c->nx;
         m.ny = c->ny;
         m.nz = c->nz;
@@ -454,9 +476,9 @@ int note_halo_codes(fdtd_ctx *c, int side, const uint8_t *codes)
         const int y = side == 0 ? c->s0 - depth + r : c->s0 + c->sn + r;
         if (y < 0 || y >= c->gn) continue;
         for (int k = 0; k < 2; ++k) {
-            c->rp_host[FDTD_RP_X0][(size_t)y * 2 + k] = rp_value(c->p, row_of(codes[(size_t)r * nx + k]), true);
-            c->rp_host[FDTD_RP_XEND][(size_t)y * 2 + k] =
-                rp_value(c->p, row_of(codes[(size_t)r * nx + nx - 2 + k]), true);
+            const size_t i = (size_t)y * 2 + k - c->rp_first[FDTD_RP_X0]; // (both x faces hold the same run)
+            c->rp_host[FDTD_RP_X0][i] = rp_value(c->p, row_of(codes[(size_t)r * nx + k]), true);
+            c->rp_host[FDTD_RP_XEND][i] = rp_value(c->p, row_of(codes[(size_t)r * nx + nx - 2 + k]), true);
         }
     }
     int rc = upload_rp(c, FDTD_RP_X0);
@@ -1189,7 +1211,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
 
     c->device = opt->device;
     HIPCHK(hipSetDevice(c->device));
-    if (int rc = scratch_init(c->device)) return rc;
+    (void)scratch_init(c->device);
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
     {
@@ -1301,15 +1323,41 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     for (int i = 0; i < FDTD_MAX_CODES; ++i) c->mats[i] = def;
     if ((rc = upload_table(c))) return rc;
 
-    // setupMurBoundary on the defaults (fdtd.cu:59 runs before :65).
+    // setupMurBoundary on the defaults (fdtd.cu:59 runs before :65).  Of every plane the context holds
+    // the run its kernels read: a 2-D slab the x-face entries of its rows and of the rows around them
+    // that a multi-step pass looks at (a wave of the row-marching sweep primes its pipeline up to
+    // 2 * steps_per_pass rows below its band; a tile of the tiled sweep is up to 64 rows tall whatever
+    // the slab holds), both y-face rows, nothing of the z faces; a 3-D slab the x- and y-face entries
+    // of its planes and both z-face planes.
     const size_t gy = (size_t)p->ny, gz = (size_t)p->nz, gx = (size_t)p->nx;
-    c->rp_n[FDTD_RP_X0] = c->rp_n[FDTD_RP_XEND] = 2 * gy * gz;
-    c->rp_n[FDTD_RP_Y0] = c->rp_n[FDTD_RP_YEND] = gx * 2 * gz;
-    c->rp_n[FDTD_RP_Z0] = c->rp_n[FDTD_RP_ZEND] = gx * gy * 2;
+    c->rp_gn[FDTD_RP_X0] = c->rp_gn[FDTD_RP_XEND] = 2 * gy * gz;
+    c->rp_gn[FDTD_RP_Y0] = c->rp_gn[FDTD_RP_YEND] = gx * 2 * gz;
+    c->rp_gn[FDTD_RP_Z0] = c->rp_gn[FDTD_RP_ZEND] = gx * gy * 2;
     const float rx = rp_value(*p, def, true), ryz = rp_value(*p, def, false);
     for (int f = 0; f < 6; ++f) {
-        c->rp_host[f].assign(c->rp_n[f], (f % 3 == 0) ? rx : ryz);
-        if ((rc = dev_alloc(c, &c->rp[f], c->rp_n[f]))) return rc;
+        const int axis = f % 3;
+        size_t first = 0, n = c->rp_gn[f];
+        if (c->is2d()) {
+            if (axis == 0) {
+                const long margin = 64 + 2 * kMaxStepsPerPass + 16;
+                const long lo = std::max(0L, (long)c->s0 - margin), hi = std::min((long)c->gn, (long)c->s0 + c->sn + margin);
+                first = 2 * (size_t)lo;
+                n = 2 * (size_t)(hi - lo);
+            } else if (axis == 2) {
+                n = 0;
+            }
+        } else if (axis != 2) {
+            const size_t per_plane = axis == 0 ? 2 * gy : 2 * gx;
+            first = (size_t)c->s0 * per_plane;
+            n = (size_t)c->sn * per_plane;
+        }
+        c->rp_first[f] = first;
+        c->rp_n[f] = n;
+        c->rp_default[f] = axis == 0 ? rx : ryz;
+        c->rp_host[f].assign(n, c->rp_default[f]);
+        if (n == 0) continue;
+        if ((rc = dev_alloc(c, &c->rp_store[f], n))) return rc;
+        c->rp[f] = c->rp_store[f] - first;
         if ((rc = upload_rp(c, f))) return rc;
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1476,23 +1524,28 @@ int fdtd_load_materials(fdtd_ctx *c, const char *specs_path, const char *pgm_dir
 
 int fdtd_set_rp(fdtd_ctx *c, int face, const float *data, size_t count)
 {
-    if (face < 0 || face > 5 || count != c->rp_n[face]) {
-        set_error("fdtd_set_rp: bad face or count");
+    if (face < 0 || face > 5 || count != c->rp_gn[face] || !data) {
+        set_error("fdtd_set_rp: bad face, or count is not the size of the whole plane");
         return -3;
     }
     if (use_device(c)) return -10;
-    c->rp_host[face].assign(data, data + count);
+    // the context keeps the entries its kernels read (all of them on a whole 3-D grid)
+    const float *run = data + c->rp_first[face];
+    c->rp_host[face].assign(run, run + c->rp_n[face]);
     if (face == FDTD_RP_X0 || face == FDTD_RP_XEND) c->rp_from_codes = false; // the caller's plane stands
     return upload_rp(c, face);
 }
 
 int fdtd_get_rp(fdtd_ctx *c, int face, float *data, size_t count)
 {
-    if (face < 0 || face > 5 || count != c->rp_n[face]) {
-        set_error("fdtd_get_rp: bad face or count");
+    if (face < 0 || face > 5 || count != c->rp_gn[face] || !data) {
+        set_error("fdtd_get_rp: bad face, or count is not the size of the whole plane");
         return -3;
     }
-    std::memcpy(data, c->rp_host[face].data(), count * sizeof(float));
+    // entries the context does not hold read as the values derived from the defaults
+    std::fill(data, data + c->rp_first[face], c->rp_default[face]);
+    std::memcpy(data + c->rp_first[face], c->rp_host[face].data(), c->rp_n[face] * sizeof(float));
+    std::fill(data + c->rp_first[face] + c->rp_n[face], data + count, c->rp_default[face]);
     return 0;
 }
 
@@ -1517,29 +1570,31 @@ int fdtd_setup_mur_from_materials(fdtd_ctx *c)
         if (c->codes_host.empty()) return c->mats[kDefaultCode];
         return c->mats[c->codes_host[((size_t)lz * (c->is2d() ? c->sn : ny) + ly) * nx + x]];
     };
-    for (int z = 0; z < nz; ++z)
-        for (int y = 0; y < ny; ++y) {
-            if (!held(y, z)) continue;
+    // entry r of the whole plane of `face` (held cells lie inside the run the context keeps)
+    auto at = [&](int face, size_t r) -> float & { return c->rp_host[face][r - c->rp_first[face]]; };
+    const int z_lo = c->is2d() ? 0 : c->s0, z_hi = c->is2d() ? 1 : c->s0 + c->sn;
+    const int y_lo = c->is2d() ? c->s0 : 0, y_hi = c->is2d() ? c->s0 + c->sn : ny;
+    for (int z = z_lo; z < z_hi; ++z)
+        for (int y = y_lo; y < y_hi; ++y)
             for (int k = 0; k < 2; ++k) {
                 const size_t r = ((size_t)z * ny + y) * 2 + k;
-                c->rp_host[FDTD_RP_X0][r] = rp_value(c->p, mat(k, y, z), true);
-                c->rp_host[FDTD_RP_XEND][r] = rp_value(c->p, mat(nx - 2 + k, y, z), true);
+                at(FDTD_RP_X0, r) = rp_value(c->p, mat(k, y, z), true);
+                at(FDTD_RP_XEND, r) = rp_value(c->p, mat(nx - 2 + k, y, z), true);
             }
-        }
-    for (int z = 0; z < nz; ++z)
+    for (int z = z_lo; z < z_hi; ++z)
         for (int k = 0; k < 2; ++k)
             for (int x = 0; x < nx; ++x) {
                 const size_t r = ((size_t)z * 2 + k) * nx + x;
-                if (held(k, z)) c->rp_host[FDTD_RP_Y0][r] = rp_value(c->p, mat(x, k, z), false);
-                if (held(ny - 2 + k, z)) c->rp_host[FDTD_RP_YEND][r] = rp_value(c->p, mat(x, ny - 2 + k, z), false);
+                if (held(k, z)) at(FDTD_RP_Y0, r) = rp_value(c->p, mat(x, k, z), false);
+                if (held(ny - 2 + k, z)) at(FDTD_RP_YEND, r) = rp_value(c->p, mat(x, ny - 2 + k, z), false);
             }
     if (!c->is2d())
         for (int k = 0; k < 2; ++k)
             for (int y = 0; y < ny; ++y)
                 for (int x = 0; x < nx; ++x) {
                     const size_t r = ((size_t)k * ny + y) * nx + x;
-                    if (held(y, k)) c->rp_host[FDTD_RP_Z0][r] = rp_value(c->p, mat(x, y, k), false);
-                    if (held(y, nz - 2 + k)) c->rp_host[FDTD_RP_ZEND][r] = rp_value(c->p, mat(x, y, nz - 2 + k), false);
+                    if (held(y, k)) at(FDTD_RP_Z0, r) = rp_value(c->p, mat(x, y, k), false);
+                    if (held(y, nz - 2 + k)) at(FDTD_RP_ZEND, r) = rp_value(c->p, mat(x, y, nz - 2 + k), false);
                 }
     for (int f = 0; f < 6; ++f) {
         int rc = upload_rp(c, f);
@@ -1906,18 +1961,21 @@ int fdtd_halo_get(fdtd_ctx *c, int side, float *dst, size_t count)
 }
 int fdtd_halo_get_noalloc(fdtd_ctx *c, int side, float *dst, size_t count)
 {
+    // Only the packed block of the multi-step mode is staged; the one-row (2-D) and one-plane (3-D)
+    // forms copy straight out of the field arrays, whatever their size.
+    if (!c->deep()) return halo_copy(c, side, dst, count, true, nullptr);
     if (count > kScratchFloats) {
         set_error("fdtd_halo_get_noalloc: the block exceeds the 4 MiB (1048576 floats) of built-in staging memory; "
                   "use fdtd_halo_get");
         return -3;
     }
     if (use_device(c)) return -10;
-    float *stage = g_scratch[c->device];
+    float *stage = scratch_of(c->device);
     if (!stage) {
-        set_error("fdtd_halo_get_noalloc: no staging memory on this device");
+        set_error("fdtd_halo_get_noalloc: no staging memory on this device (hipGetSymbolAddress failed at fdtd_create)");
         return -10;
     }
-    if (c->deep() && count > 0) {
+    if (count > 0) {
         // the last float holds the tail of the code bytes and may be written in part only; the
         // array keeps what the previous call (of any context on this GPU) left there
         HIPCHK(hipMemsetAsync(stage + count - 1, 0, sizeof(float), c->stream));

@@ -229,8 +229,9 @@ struct Fused3D {
 // cf[cell] = mur_coefs(...) of the face cell and the cell one step inside.  Face cells are numbered
 // z * ny + y (x faces), z * nx + x (y faces), y * nx + x (z faces).
 struct MurCoefs {
-    const float *rp;
-    float *cf;
+    const float *rp;        // indexed with the plane's global layout (the caller holds cells first .. first + count - 1)
+    float *cf;              // likewise, by face cell
+    long long first, count; // the face cells to do
     int face;   // FDTD_RP_*
     int nx, ny, nz;
     float dt, du, mu0, eps0;

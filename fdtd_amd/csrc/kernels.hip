@@ -264,9 +264,8 @@ __global__ __launch_bounds__(256) void fdtd3d_mur_coefs(const MurCoefs a)
 {
     const int axis = a.face % 3;
     const bool high = a.face >= 3;
-    const long n = axis == 0 ? (long)a.ny * a.nz : axis == 1 ? (long)a.nx * a.nz : (long)a.nx * a.ny;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n) return;
+    const long t = a.first + (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.first + a.count) return;
     float r0, r1; // the two rp entries of the cell pair, lower index first (layouts of fdtd.cu:952-1001)
     if (axis == 0) {
         r0 = a.rp[t * 2];
@@ -419,9 +418,8 @@ void launch_halo_deep(const HaloDeep &a, void *stream)
 
 void launch_mur_coefs(const MurCoefs &a, void *stream)
 {
-    const int axis = a.face % 3;
-    const long n = axis == 0 ? (long)a.ny * a.nz : axis == 1 ? (long)a.nx * a.nz : (long)a.nx * a.ny;
-    hipLaunchKernelGGL(fdtd3d_mur_coefs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, S(stream), a);
+    if (a.count <= 0) return;
+    hipLaunchKernelGGL(fdtd3d_mur_coefs, dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, S(stream), a);
 }
 
 void launch_expand_codes(const ExpandCodes &a, void *stream)

@@ -149,7 +149,13 @@ int fdtd_load_materials(fdtd_ctx *ctx, const char *specs_path, const char *pgm_d
  * map (fdtd.cu:922-931; `count` = cells of the slab held, x fastest). */
 int fdtd_set_material(fdtd_ctx *ctx, int code, float sigma, float eps_s, float eps_inf, float tau_d);
 int fdtd_set_codes(fdtd_ctx *ctx, const uint8_t *codes, size_t count);
-/* Replace one rp plane (layouts of fdtd.cu:952-1001, global extents). */
+/* Replace one rp plane (layouts of fdtd.cu:952-1001, global extents: `count`
+ * is the size of the whole plane whatever the context holds).  A context keeps
+ * the entries its kernels read -- a slab those of its own rows or planes and of
+ * the neighbours' rows a multi-step pass recomputes, a 2-D context none of the
+ * z faces -- so the memory a plane takes follows the slab, not the grid.
+ * fdtd_get_rp() returns the held entries and, everywhere else, the value
+ * derived from the defaults. */
 int fdtd_set_rp(fdtd_ctx *ctx, int face, const float *data, size_t count);
 int fdtd_get_rp(fdtd_ctx *ctx, int face, float *data, size_t count);
 /* setupMurBoundary (fdtd.cu:942-1024) evaluated on the materials now loaded
@@ -247,13 +253,15 @@ size_t fdtd_halo_count(const fdtd_ctx *ctx);
 int fdtd_halo_get(fdtd_ctx *ctx, int side, float *dst, size_t count);
 int fdtd_halo_put(fdtd_ctx *ctx, int side, const float *src, size_t count);
 /* No counterpart in the reference.  For callers that cannot allocate device
- * memory (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc): fdtd_halo_get() with the packed block of the multi-step
- * mode staged in a 4 MiB array that is part of the library's code object
- * instead of buffers allocated on first use.  Same arguments and result as
- * fdtd_halo_get(); fails when count exceeds 1048576 floats.  The array is one
- * per GPU and shared by every context on it: two calls that overlap on one GPU
- * race. */
+ * memory (tight serving loops, harnesses that forbid hipMalloc):
+ * fdtd_halo_get() with the packed block of the multi-step mode staged in a
+ * 4 MiB array that is part of the library's code object instead of buffers
+ * allocated on first use.  Same arguments and result as fdtd_halo_get(); the
+ * packed block must not exceed 1048576 floats (the one-row and one-plane forms
+ * of the other kernels need no staging and have no limit).  Like
+ * fdtd_halo_get() it synchronises the stream and copies to pageable host
+ * memory, so it cannot be captured into a HIP graph.  The array is one per GPU
+ * and shared by every context on it: two calls that overlap on one GPU race. */
 int fdtd_halo_get_noalloc(fdtd_ctx *ctx, int side, float *dst, size_t count);
 
 /* RCCL form of the exchange: rank 0 creates an id (128 bytes), every rank
@@ -273,7 +281,9 @@ int fdtd_comm_init(fdtd_ctx *ctx, const char id[128], int rank, int world);
  * on one GPU or on several; messages are device-to-device copies after a
  * rendezvous of the two threads.  fdtd_comm_local_group() creates the shared rendezvous object for
  * `world` ranks, every rank passes it to fdtd_comm_init_local(); free it after
- * the contexts are destroyed. */
+ * the contexts are destroyed.  An exchange that fails on any rank (time limit,
+ * ranks that disagree on the message size, a HIP error) leaves the group
+ * unusable: every later exchange through it reports an error. */
 int fdtd_comm_local_group(int world, void **group);
 void fdtd_comm_local_group_free(void *group);
 int fdtd_comm_init_local(fdtd_ctx *ctx, void *group, int rank, int world);

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import DATA
+from conftest import DATA, GOLDEN
 
 
 def f32(x):
@@ -118,3 +118,74 @@ def test_omp_threads_do_not_change_results(oracle):
     b.step(30, threads=4)
     for f in range(9):
         assert np.array_equal(a.field(f), b.field(f), equal_nan=True)
+
+
+# ---- vectors recorded from the reference's own host functions (tests/golden/make_reference_host_vectors.py)
+
+def _host_vectors():
+    import json
+    with open(os.path.join(GOLDEN, "reference_host_vectors.json")) as f:
+        return json.load(f)
+
+
+def _u32(a):
+    return np.ascontiguousarray(a, dtype=np.float32).ravel().view(np.uint32)
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a, dtype=np.float32).tobytes()).hexdigest()
+
+
+def test_reference_host_vectors_params_and_sources(oracle, tmp_path):
+    """initParamsWithPath + setupSources as recorded from the reference: every scalar bit for bit,
+    all 16384 jz samples (their non-zero prefix spelled out, the whole table by hash) -- the oracle
+    and the library's own parser."""
+    import fdtd_amd
+    import test_reference_host as T
+    for rec in _host_vectors()["params"]:
+        path = T.write_params(tmp_path, **rec["changes"])
+        for p, njz in ((oracle.load_params(path), oracle.JZ_TABLE), (fdtd_amd.params_load(path), 512)):
+            for name, want in rec["ints"].items():
+                assert getattr(p, name) == want, name
+            for name, want in rec["floats_u32"].items():
+                assert int(_u32(getattr(p, name))[0]) == want, name
+            assert list(p.sources[:len(rec["sources"])]) == rec["sources"]
+            prefix = np.array(rec["jz_nonzero_prefix_u32"], dtype=np.uint32)
+            jz = _u32(p.jz[:])
+            assert np.array_equal(jz[:len(prefix)], prefix) and not np.any(jz[len(prefix):njz])
+            if njz == oracle.JZ_TABLE:
+                assert _sha(p.jz[:]) == rec["jz_sha256"]
+
+
+def test_reference_host_vectors_materials_and_mur(oracle, tmp_path):
+    """loadMaterials and setupMurBoundary as recorded from the reference."""
+    import test_reference_host as T
+    from fdtd_amd import binding
+    vec = _host_vectors()
+    for rec in vec["materials"]:
+        nx, ny, nz = rec["dims"]
+        d = tmp_path / f"pgm_{nx}"
+        d.mkdir()
+        if "rp_sha256" in rec:
+            _, present = binding.read_material_specs(T.SPECS)
+            codes = np.random.default_rng(42).choice(np.flatnonzero(present), size=(nz, ny, nx))
+            for iz in range(nz):
+                T.write_pgm(d / f"v1_{iz + 1:05d}.pgm", nx, ny, codes[iz])
+        else:
+            for iz in range(nz):
+                os.symlink(os.path.join(DATA, "pgmdata", "v1_00800.pgm"), d / f"v1_{iz + 1:05d}.pgm")
+        o = oracle.Oracle(oracle.make_params(nx, ny, nz, [(5, 5, 1)]))
+        o.load_materials(T.SPECS, str(d))
+        assert [_sha(o.material(w)) for w in range(4)] == rec["sha256"], rec["dims"]
+        if "rp_sha256" in rec:
+            o.setup_mur()
+            assert [_sha(o.rp(f)) for f in range(6)] == rec["rp_sha256"]
+            assert [[int(v) for v in _u32(o.rp(f)[:8])] for f in range(6)] == rec["rp_first8_u32"]
+    p = binding.params_load(T.SHIPPED)
+    for rec in vec["mur_defaults"]:
+        sg, es, ei, tau = rec["material"]
+        o = oracle.Oracle(oracle.make_params(9, 8, 7, [(4, 4, 4)], sigma=sg, eps_s=es, eps_i=ei, tau_d=tau))
+        for face in range(6):
+            assert int(_u32(o.rp(face)[0])[0]) == rec["rp_u32"][face], (rec["material"], face)
+            assert int(_u32(binding.rp_value(p, face % 3 == 0, sg, es, ei, tau))[0]) == rec["rp_u32"][face]

@@ -186,6 +186,76 @@ def test_rp_planes_from_loaded_materials_per_slab(oracle, monkeypatch, dims, ker
         group.close()
 
 
+@pytest.mark.timeout(900)
+def test_2d_two_slabs_of_the_8_gpu_shape_65536x8192_deep_halo(oracle, monkeypatch):
+    """What one rank of the 65536 x 65536 grid holds on 8 GPUs: two neighbouring slabs of
+    65536 x 8192 (rows 24576.. and 32768.. of the grid, ranks 0 and 1 of a world of two), 8 steps
+    per pass, deep-halo blocks of 6 x 8 x 65536 floats + 8 x 65536 code bytes (13.1 MB) through
+    the in-process transport, overlap on, sources on both sides of the cut.  60 steps (7 passes
+    of 8, one of 4): the window around the sources equals an oracle window bit for bit, nothing
+    lies outside the light cone, and a slab takes its 49 bytes per cell plus O(faces) -- no
+    plane of global extent.  Then a block of that size through RCCL (one-rank communicator)."""
+    import ctypes
+    import gc
+    gc.collect()
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    if free_bytes() < 90e9:
+        pytest.skip("needs 90 GB of free HBM")
+    monkeypatch.setenv("FDTD_HALO_OVERLAP", "1")
+    monkeypatch.setenv("FDTD_LOCAL_TIMEOUT", "60")
+    n, rows, cut, steps, w = 65536, 8192, 32768, 60, 256
+    sx = 40000
+    srcs = [(sx, cut - 1, 0), (sx + 5, cut + 2, 0)]
+    pa = fdtd_amd.make_params(n, n, 1, srcs)
+    group = B.LocalGroup(2)
+    before = free_bytes()
+    slabs = [fdtd_amd.Solver(pa, ecoef=CON, kernel=MS8, slab=(cut - rows + r * rows, rows)) for r in range(2)]
+    try:
+        for r, sv in enumerate(slabs):
+            sv.comm_init_local(group.handle, r, 2)
+            assert sv.sweep_kernel_name == "fdtd2d_sweep_tb" and sv.steps_per_pass == 8
+            assert sv.halo_count == 6 * 8 * n + 8 * n // 4
+            sv.set_probes([(sx, cut - 1, 0), (sx, cut, 0)], capacity=steps)
+
+        def rank(r):
+            slabs[r].step(steps)
+            slabs[r].sync()
+
+        run_ranks(rank, 2)
+        used = before - free_bytes()
+        assert used < 2 * 27.5e9, used          # 49 B x 537 M cells = 26.3 GB per slab, halos and faces on top
+        o = oracle.Oracle(oracle.make_params(w, w, 1, [(w // 2, w // 2, 0), (w // 2 + 5, w // 2 + 3, 0)]), ecoef=CON)
+        o.step(steps, threads=8)
+        h = w // 2
+        for fid in (B.HX, B.HY, B.DZ, B.EZ):
+            # window rows cut-1-h .. cut-1+h-1: the last h+1 rows of slab 0, the first h-1 of slab 1
+            win = np.concatenate([slabs[0].window(fid, rows - h - 1, h + 1, sx - h, w),
+                                  slabs[1].window(fid, 0, h - 1, sx - h, w)], axis=0)
+            util.assert_bits_equal(win, np.asarray(o.field(fid)[0]), B.FIELD_NAMES[fid])
+            assert np.any(win[:h + 1] != 0) and np.any(win[h + 1:] != 0)
+            for sv in slabs:     # a frame around the light cone, and the far corners of both slabs
+                for row0, x0 in ((0, 0), (0, n - w), (rows - w, 0), (rows - w, n - w), (rows // 2, sx - h),
+                                 (rows - w if sv is slabs[1] else 0, sx - h), (rows - w if sv is slabs[0] else 0, sx - 2 * w),
+                                 (rows - w if sv is slabs[0] else 0, sx + w + 5)):
+                    assert not np.any(sv.window(fid, row0, w, x0, w)), (B.FIELD_NAMES[fid], row0, x0)
+        got = slabs[0].read_probes(0, steps) + slabs[1].read_probes(0, steps)
+        assert np.all(np.isfinite(got)) and np.all(got[-1][:, 3] != 0)
+        # the same block through ncclSend/ncclRecv: slab 0 with a one-rank RCCL communicator sends
+        # its packed lower boundary rows to itself
+        slabs[0].comm_init(B.comm_unique_id(), 0, 1)
+        slabs[0].comm_selftest()
+    finally:
+        for sv in slabs:
+            sv.close()
+        group.close()
+
+
 def test_multi_step_slab_without_a_communicator_refuses_to_outrun_its_halos():
     s = fdtd_amd.Solver(fdtd_amd.make_params(300, 100, 1, [(150, 50, 0)]), ecoef=CON, kernel=MS3, slab=(0, 50))
     s.step(3)

@@ -37,35 +37,60 @@ BYTES_PER_CELL_3D = 97   # read 3 H + 6 E + 6 D (60) + code (1); write 3 H + 3 E
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak
 
 
-def cpu_baseline(nx, ny, budget_s=20.0):
+def cpu_baseline(nx, ny, nz=1, budget_s=20.0):
     """Oracle (CPU restatement, OpenMP over rows) on a bounded sample: the same
     vacuum + centre-source workload on a smaller grid for about budget_s seconds."""
     from oracle import oracle
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
-    p = oracle.make_params(nx, ny, 1, [(nx // 2, ny // 2, 0)])
+    p = oracle.make_params(nx, ny, nz, [(nx // 2, ny // 2, nz // 2)])
     o = oracle.Oracle(p, ecoef=oracle.ECOEF_CONSISTENT)
-    o.step(10, threads)                                  # touch the pages, spin up the thread pool
-    t_probe = o.time_steps(20, threads) / 20
+    o.step(3 if nz > 1 else 10, threads)                 # touch the pages, spin up the thread pool
+    probe = 5 if nz > 1 else 20
+    t_probe = o.time_steps(probe, threads) / probe
     steps = max(3, min(5000, int(budget_s / max(t_probe, 1e-6))))
     sec = o.time_steps(steps, threads)
+    shape = f"{nx}x{ny}x{nz} 3-D" if nz > 1 else f"{nx}x{ny} 2-D TMz"
     return {
-        "value": nx * ny * steps / sec / 1e6,
+        "value": nx * ny * nz * steps / sec / 1e6,
         "unit": "Mcell-updates/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"CPU oracle (C, -O2 -ffp-contract=off, OpenMP), {nx}x{ny} 2-D TMz vacuum + centre source, "
+        "sample": f"CPU oracle (C, -O2 -ffp-contract=off, OpenMP), {shape} vacuum + centre source, "
                   f"{steps} steps, {sec:.1f} s",
     }
 
 
+KERNEL_SOURCES = {"fdtd2d_sweep_tb": "sweep2d_tb.hip", "fdtd2d_sweep": "sweep2d.hip", "fdtd2d_tile": "sweep2d_tile.hip",
+                  "fdtd3d_sweep": "sweep3d.hip", "fdtd3d_sweep_tb": "sweep3d_tb.hip"}
+
+
+def kernel_source_sha16(kernel):
+    """Fingerprint of the source a kernel is built from (its .hip file and the two headers every
+    kernel includes): a committed PMC measurement is only quoted for the code it was taken with."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in (KERNEL_SOURCES.get(kernel, ""), "device_math.h", "internal.h"):
+        try:
+            with open(os.path.join(ROOT, "fdtd_amd", "csrc", name), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload, kernel, spp):
-    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes, if any."""
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes, if any -- and only if the
+    kernel's source is still the one the passes were taken with (None otherwise: a stale figure is
+    worse than none)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(f"{workload} [{kernel} x{spp}]", {}).get("hbm_bytes_per_launch")
+            entry = json.load(f).get(f"{workload} [{kernel} x{spp}]", {})
     except (OSError, ValueError):
         return None
+    if entry.get("kernel_source_sha16") != kernel_source_sha16(kernel):
+        return None
+    return entry.get("hbm_bytes_per_launch")
 
 
 def issue_bound(solver, k, kernel_ms):
@@ -131,7 +156,7 @@ def main():
     ap.add_argument("--nz", type=int, default=1, help="> 1 selects the 3-D path (z planes per GPU)")
     ap.add_argument("--chunk-rows", type=int, default=0)
     ap.add_argument("--kernel", choices=["auto", "split", "fused", "multistep", "tile"], default="auto")
-    ap.add_argument("--steps-per-pass", type=int, default=0, help="multistep kernel: time steps per pass (2..4)")
+    ap.add_argument("--steps-per-pass", type=int, default=0, help="multi-step kernels: time steps per pass (2..8; 0 = the library's choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--device", type=int, default=-1, help="GPU ordinal (default: LOCAL_RANK)")
     ap.add_argument("--snapshot-every", type=int, default=0,
@@ -397,7 +422,7 @@ def main():
             solver.close()
             out["roofline_one_step"] = one_step_leg(params, local_rank, cells_per_rank)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(4096, 4096) if not is3d else None
+            out["cpu_baseline"] = cpu_baseline(4096, 4096) if not is3d else cpu_baseline(256, 256, 256)
         print(json.dumps(out), flush=True)
 
     solver.close()

@@ -1688,11 +1688,25 @@ int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
 int fdtd_sweep_work(const fdtd_ctx *c, int64_t *waves, int64_t *row_iterations)
 {
     if (c->tile) {
-        // one workgroup of 16 waves per tile of 48 x (64 - 2 * steps) owned cells, one iteration per step
+        // one workgroup per tile of 48 x (tile rows - 2 * steps) owned cells, one wave per 4 rows
+        // (two words per thread: per 8), one iteration per step; a slab whose edge rows go in launches
+        // of their own (halo exchange beside the interior sweep) is counted launch by launch
         const int K = c->tb_steps;
-        const int64_t tiles = (int64_t)(((c->nx + 3) / 4 + 11) / 12) * ((c->sn + 63 - 2 * K) / (64 - 2 * K));
-        if (waves) *waves = tiles * 16;
-        if (row_iterations) *row_iterations = tiles * 16 * K;
+        const int edge = (c->tb_steps + 15) / 16 * 16;
+        const Split sp = split_of(c, edge, c->tb_rows);
+        const int lo = sp.on && sp.lower ? edge : 0, hi = sp.on && sp.upper ? c->sn - edge : c->sn;
+        const int ranges[3][2] = {{0, lo}, {lo, hi}, {hi, c->sn}};
+        int64_t w = 0;
+        for (const auto &r : ranges) {
+            if (r[1] <= r[0]) continue;
+            const int rows = sweep2d_tile_rows(c->nx, r[1] - r[0], K);
+            const int ty = rows == 642 ? 64 : rows, waves_per_tile = rows == 642 ? 8 : rows / 4;
+            if (ty - 2 * K < 1) continue;
+            const int64_t tiles = (int64_t)(((c->nx + 3) / 4 + 11) / 12) * ((r[1] - r[0] + ty - 2 * K - 1) / (ty - 2 * K));
+            w += tiles * waves_per_tile;
+        }
+        if (waves) *waves = w;
+        if (row_iterations) *row_iterations = w * K;
         return 0;
     }
     if (!c->deep()) {

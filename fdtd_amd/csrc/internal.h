@@ -130,6 +130,7 @@ struct SweepTB {
     // faces of every band first (2 * band + side), the inner strips after them band by band.
     int faces_first;
     int strips;                           // waves across a row (kTbOwnWords owned words each)
+    long long nwaves;                     // bands x strips (set by the launcher): positions of the padded last block beyond it leave
     int map;                              // 0: waves numbered band by band; 1: each XCD walks its own panel of strips
     int strips_per_xcd;                   // map 1: ceil(strips / 8)
 };
@@ -287,6 +288,8 @@ int launch_sweep2d_tb(const SweepTB &a, int steps, void *stream);
 const char *sweep2d_tb_kernel_name();
 // Returns 0, or -1 when the pass cannot be tiled (steps outside 1 .. kMaxStepsPerPass, no rows).
 int launch_sweep2d_tile(const SweepTile &t, void *stream);
+// Tile height the launcher takes for a launch over `rows_of_launch` rows: 32, 64, or 642 (64 rows, two words per thread).
+int sweep2d_tile_rows(int nx, int rows_of_launch, int steps);
 const char *sweep2d_tile_kernel_name();
 void launch_sweep3d(const Fused3D &a, void *stream);
 void launch_mur2d(const Mur2D &a, void *stream);

@@ -99,6 +99,9 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     int strip, band;
     if (a.map == 0) {
         long wv = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+        // positions past the last wave of the launch (the last block is padded to WPB waves): the
+        // remaps below would turn them into waves that exist
+        if (wv >= a.nwaves) return;
         if (a.nfirst > 0) {
             // the waves listed in first[] (ascending) go first, the others follow in their order
             if (wv < a.nfirst) {
@@ -477,19 +480,21 @@ template <int K> int launch_k(const SweepTB &a, hipStream_t stream)
     else
         blocks = 8 * ((bands * a.strips_per_xcd + wpb - 1) / wpb);
     const dim3 grid((unsigned)blocks), block((unsigned)(wpb * 64));
+    SweepTB b = a;
+    b.nwaves = bands * a.strips;
     // Loads without the nontemporal hint: the lines two adjacent waves share stay in L2 for the
     // second of them (16384^2, K = 8: 3.32 ms per pass against 3.42 with the hint).  The hinted
     // form is kept for K = 8 on a single material as a tuning reference (FDTD_TB_PLAIN_LOADS=0).
     static const bool hinted = std::getenv("FDTD_TB_PLAIN_LOADS") && !std::atoi(std::getenv("FDTD_TB_PLAIN_LOADS"));
     if (one) {
         if (K == 8 && hinted)
-            hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, K != 8, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, K != 8, false>), grid, block, 0, stream, b);
         else
-            hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, true, false>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, true, false>), grid, block, 0, stream, b);
     } else if (wide) {
-        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, true>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, true>), grid, block, 0, stream, b);
     } else {
-        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, false>), grid, block, 0, stream, a);
+        hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, false>), grid, block, 0, stream, b);
     }
     return 0;
 }

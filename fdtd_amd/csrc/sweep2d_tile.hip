@@ -308,15 +308,19 @@ template <int WX, int RT, int V> int launch_tile(SweepTile t, hipStream_t stream
 // again once there are several rounds of them (two workgroups per CU then cover each other's
 // barriers: 2048^2 311 against 300 Gcell-updates/s); in between 64 rows (1024 threads, fewer
 // recomputed rows: 768^2 2.8 against 3.7 us per step).
+int sweep2d_tile_rows(int nx, int rows_of_launch, int steps)
+{
+    static const int forced = std::getenv("FDTD_TILE_ROWS") ? std::atoi(std::getenv("FDTD_TILE_ROWS")) : 0;
+    if (forced) return forced;
+    const long nw = (nx + 3) / 4, n = rows_of_launch;
+    const long tall = ((nw + 11) / 12) * ((n + (64 - 2 * steps) - 1) / (64 - 2 * steps));
+    return (tall >= 256 && tall <= 1100) ? 64 : 32; // (1536^2, 1024 tall tiles: 268 against 235; 1792^2, 1444: 282 against 291)
+}
+
 int launch_sweep2d_tile(const SweepTile &t, void *stream)
 {
     if (t.steps < 1 || t.steps > kMaxStepsPerPass) return -1;
-    static const int forced = std::getenv("FDTD_TILE_ROWS") ? std::atoi(std::getenv("FDTD_TILE_ROWS")) : 0;
-    const long nw = (t.b.g.nx + 3) / 4, n = t.b.y_end - t.b.y_begin;
-    const long tall = ((nw + 11) / 12) * ((n + (64 - 2 * t.steps) - 1) / (64 - 2 * t.steps));
-    int rows = (tall >= 256 && tall <= 1100) ? 64 : 32; // (1536^2, 1024 tall tiles: 268 against 235; 1792^2, 1444: 282 against 291)
-    if (forced) rows = forced;
-    switch (rows) {
+    switch (sweep2d_tile_rows(t.b.g.nx, t.b.y_end - t.b.y_begin, t.steps)) {
     case 32: return launch_tile<16, 32, 1>(t, (hipStream_t)stream);
     case 64: return launch_tile<16, 64, 1>(t, (hipStream_t)stream);
     case 642: return launch_tile<16, 32, 2>(t, (hipStream_t)stream); // 64 rows, two words per thread

@@ -43,7 +43,9 @@ tpath = os.path.join(ROOT, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 h = summary["hbm_bytes_per_launch"]
 avg = [float(r["AverageNs"]) for r in summary.get("kernel_stats", []) if name in r["Name"] and (kernel.endswith("<") and name + "<" in r["Name"] or not kernel.endswith("<"))]
-traffic[key] = {"hbm_bytes_per_launch": h["total"], "read_corrected": h["read_corrected"], "write": h["write"],
+sys.path.insert(0, ROOT)
+from bench import kernel_source_sha16
+traffic[key] = {"kernel_source_sha16": kernel_source_sha16(name), "hbm_bytes_per_launch": h["total"], "read_corrected": h["read_corrected"], "write": h["write"],
                 "kernel": name, "steps_per_launch": steps, "kernel_avg_ns_rocprofv3": avg[0] if avg else None,
                 "l2_hit_rate": summary.get("l2_hit_rate"),
                 "source": f"profiles/{tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH_SIZE x2 on gfx950)"}

@@ -49,3 +49,15 @@ def test_halo_get_noalloc_rejects_blocks_beyond_its_staging_memory():
     with pytest.raises(fdtd_amd.FdtdError, match="4 MiB"):
         s.halo_get_noalloc(0)
     assert s.halo_get(0).size == s.halo_count       # the allocating form still serves it
+
+
+def test_halo_get_noalloc_3d_plane_above_the_staging_limit_is_not_staged():
+    # 3 * 640 * 600 floats > 1 Mi floats: the one-plane form copies straight out of the field arrays
+    s = fdtd_amd.Solver(fdtd_amd.make_params(640, 600, 12, [(320, 300, 6)]), ecoef=B.ECOEF_CONSISTENT, kernel=B.KERNEL_FUSED,
+                        slab=(4, 4))
+    s.step(6)
+    assert s.halo_count > (1 << 20)
+    for side in (0, 1):
+        got, want = s.halo_get_noalloc(side), s.halo_get(side)
+        assert np.abs(want).max() > 0 or side == 0
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

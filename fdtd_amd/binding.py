@@ -75,6 +75,8 @@ SYMBOLS = [
     ("fdtd_profile_begin", _I, [_VP, _I]),
     ("fdtd_profile_read", _I, [_VP, _VP, _I, C.POINTER(_I)]),
     ("fdtd_profile_read_launches", _I, [_VP, _VP, _VP, _I, C.POINTER(_I)]),
+    ("fdtd_profile_waves_begin", _I, [_VP, C.c_int64]),
+    ("fdtd_profile_waves_read", _I, [_VP, _VP, C.c_int64, C.POINTER(C.c_int64)]),
     ("fdtd_sweep_work", _I, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("fdtd_sweep_kernel_name", C.c_char_p, [_VP]),
     ("fdtd_read_field", _I, [_VP, _I, _I, _VP, _SZ]),
@@ -269,6 +271,17 @@ class Solver:
         n = _I(0)
         _check(self.lib.fdtd_profile_read_launches(self._ctx, ms.ctypes.data, steps.ctypes.data, capacity, C.byref(n)))
         return ms[:n.value], steps[:n.value]
+
+    def profile_waves_begin(self, capacity):
+        """Arm the wave timeline for the next launch of the multi-step sweep."""
+        _check(self.lib.fdtd_profile_waves_begin(self._ctx, capacity))
+
+    def profile_waves_read(self, capacity):
+        """Rows {start, end (100 MHz ticks), strip | band << 32, flags} per launch position."""
+        t = np.zeros((capacity, 4), dtype=np.uint64)
+        n = C.c_int64(0)
+        _check(self.lib.fdtd_profile_waves_read(self._ctx, t.ctypes.data, capacity, C.byref(n)))
+        return t[:n.value]
 
     @property
     def steps_per_pass(self):

@@ -156,6 +156,9 @@ struct fdtd_ctx {
     // per-launch sweep timing
     std::vector<hipEvent_t> prof_ev;
     std::vector<int> prof_steps; // time steps each timed launch advanced
+    unsigned long long *wave_trace = nullptr; // fdtd_profile_waves_begin: 4 words per wave of the next multi-step launch
+    long wave_trace_cap = 0, wave_trace_n = 0;
+    bool wave_trace_armed = false;
     int prof_cap = 0, prof_n = 0;
 
     // snapshots: two staging sets (compact device copy + pinned host buffer), used in turn, so a new
@@ -828,9 +831,20 @@ void record_probes(fdtd_ctx *c, int mid, bool launch)
 // Rows of a launch of the multi-step sweep over [y_begin, y_end): bands of tb_rows rows, the last
 // eighth (at most 2048 rows) in bands a third as high (32 rows under tall bands)
 // (16384^2, K = 8, 96 rows: no tail 3.63 ms, 1024 rows in 16s 3.50, 2048 in 32s 3.41).
-void tb_rows_of(const fdtd_ctx *c, SweepTB &a, int y_begin, int y_end)
+void tb_rows_of(const fdtd_ctx *c, SweepTB &a, int y_begin, int y_end, int K)
 {
-    const int n = y_end - y_begin;
+    // A band on a y face runs the fully guarded copy of the loop for all its rows, which takes twice as
+    // long per row as the plain one: with bands of the common height those waves set the length of a
+    // launch of one or two rounds of waves (4096^2: 233 of 254 us).  The bands on the faces are as
+    // short as the guards allow -- 2K+1 rows at y = 0, K+2 at y = ny-1 --, the bands next to them plain.
+    static const bool short_faces = !std::getenv("FDTD_TB_SHORT_FACES") || std::atoi(std::getenv("FDTD_TB_SHORT_FACES"));
+    a.head_rows = a.last_rows = 0;
+    if (short_faces && y_end - y_begin >= 2 * c->tb_rows + 3 * K + 3) {
+        if (c->s0 + y_begin == 0) a.head_rows = 2 * K + 1;
+        if (c->s0 + y_end == c->gn) a.last_rows = K + 2;
+    }
+    const int yb = y_begin + a.head_rows;
+    const int n = y_end - a.last_rows - yb;
     // (bands of 96 rows and more: 32-row tail bands -- 16384^2 at 176 rows: 790 against 770 with 58-row ones,
     // 16384 x 32768 796 against 789, 65536 x 4096 757 against 749, 10240^2 695 against 687, tissue map 680 against 685)
     int tail = std::min(2048, n / 8), short_rows = c->tb_rows >= 96 ? 32 : std::max(4, c->tb_rows / 3);
@@ -842,7 +856,7 @@ void tb_rows_of(const fdtd_ctx *c, SweepTB &a, int y_begin, int y_end)
     a.y_end = y_end;
     a.tail_rows = tail > 0 ? short_rows : c->tb_rows;
     a.big_bands = tail > 0 ? (n - tail) / c->tb_rows : (n + c->tb_rows - 1) / c->tb_rows;
-    a.tail_begin = tail > 0 ? y_begin + a.big_bands * c->tb_rows : y_end;
+    a.tail_begin = tail > 0 ? yb + a.big_bands * c->tb_rows : y_end - a.last_rows;
 }
 
 int finish_pass(fdtd_ctx *c, const SweepTB &a, int K, const Split &sp, int lo, int hi, bool tail);
@@ -855,8 +869,10 @@ void tb_first_waves(const fdtd_ctx *c, SweepTB &a, int K)
     a.faces_first = 0;
     if (a.map != 0) return;
     std::vector<std::pair<int, int>> bands; // rows [y0, y1) of every band, in launch order
-    for (int b = 0; b < a.big_bands; ++b) bands.push_back({a.y_begin + b * a.rows, std::min(a.y_begin + (b + 1) * a.rows, a.y_end)});
-    for (int y = a.tail_begin; y < a.y_end; y += a.tail_rows) bands.push_back({y, std::min(y + a.tail_rows, a.y_end)});
+    for (long b = 0, nb = tb_band_count(a); b < nb; ++b) {
+        int y0 = 0, y1 = 0;
+        if (tb_band_rows(a, b, y0, y1)) bands.push_back({y0, y1});
+    }
     static const bool faces = !std::getenv("FDTD_TB_FACES_FIRST") || std::atoi(std::getenv("FDTD_TB_FACES_FIRST"));
     a.faces_first = (faces && a.strips > 2) ? (int)bands.size() : 0;
     std::vector<int> ids;
@@ -942,6 +958,8 @@ int pass_once(fdtd_ctx *c, int K)
     a.map = c->tb_map;
     a.strips_per_xcd = (a.strips + 7) / 8;
     a.nfirst = a.faces_first = 0;
+    a.head_rows = a.last_rows = 0;
+    a.trace = nullptr;
 
     // The rows within `edge` of a neighbour slab go first, on xstream, and the deep-halo exchange
     // follows them there while the main stream sweeps the interior.
@@ -981,6 +999,7 @@ int pass_once(fdtd_ctx *c, int K)
         if ((rc = fork_xstream(c))) return rc;
         SweepTB e = a;
         e.rows = e.tail_rows = edge;
+        e.head_rows = e.last_rows = 0;
         e.y_begin = 0;
         e.big_bands = lo > 0 ? 1 : 0;
         e.tail_begin = hi < c->sn ? hi : lo;
@@ -990,9 +1009,19 @@ int pass_once(fdtd_ctx *c, int K)
             return -3;
         }
     }
-    tb_rows_of(c, a, lo, hi);
+    tb_rows_of(c, a, lo, hi, K);
     static const bool reorder = !std::getenv("FDTD_TB_FIRST") || std::atoi(std::getenv("FDTD_TB_FIRST"));
     if (reorder) tb_first_waves(c, a, K);
+    if (c->wave_trace_armed) {
+        // one launch: its positions are bands x strips, padded to whole blocks of at most 4 waves
+        const long n = tb_band_count(a) * a.strips + 4;
+        if (n <= c->wave_trace_cap) {
+            HIPCHK(hipMemsetAsync(c->wave_trace, 0, (size_t)n * 32, c->stream));
+            a.trace = c->wave_trace;
+            c->wave_trace_n = n;
+        }
+        c->wave_trace_armed = false;
+    }
     if (prof) HIPCHK(hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream));
     if (launch_sweep2d_tb(a, K, c->stream)) {
         set_error("no multi-step kernel for this number of steps per pass");
@@ -1084,6 +1113,7 @@ void fdtd_destroy(fdtd_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (hipEvent_t ev : c->prof_ev) (void)hipEventDestroy(ev);
+    if (c->wave_trace) (void)hipFree(c->wave_trace);
     if (c->side) (void)hipStreamDestroy(c->side);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1166,21 +1196,24 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         return -3;
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->tb_rows == 0) {
-        // Rows per wave: tall bands keep the rows a wave re-marches (2K - 1 per band) cheap, short ones give
-        // the launch enough waves to keep 2048 of them in flight until its end.  Measured optimum on large
-        // grids: about 4800 waves per launch, at most 176 rows (16384^2: 176 rows 779 Gcell-updates/s, 96
-        // rows 728; 8480x15680: 96 and 112 rows 612, 64 and 128 rows 590; 12288^2: 128 rows 706, 160 rows
-        // 677; 10240^2: 112 rows 694, 96 rows 676).  Below 500 000 band-rows x strips the optimum is sharp
-        // and sits higher than that (4096^2: 32 rows 381, 16 rows 330, 48 rows 291; 5120^2: 32 rows 495,
-        // 24 rows 422, 48 rows 413; 6144^2: 48 rows 537, 32 rows 472, 64 rows 451; 4096x8192 and 8192x4096:
-        // 48 rows 515 / 536, 32 rows 464 / 496; 7168^2: 56 rows 601; 8192^2: 64 rows 649, 48 rows 590;
-        // 8704^2: 80 rows 626, 64 rows 604; 9216^2: 72 rows 651, 80 rows 643, 64 rows 628).
+        // Rows per wave, from the number of waves the GPU holds at once: 2048 (256 CUs x 2 workgroups of 4
+        // waves: 244 registers and 20 KB of LDS per wave).  A wave marches its rows plus 2K - 1 around them
+        // at about 3 us per row whatever the load (it is bound by the latency of its own dependency chain,
+        // not by bandwidth, until some 2000 of them run), so a launch takes (rounds of waves) x (rows + 2K - 1)
+        // x 3 us and wants few, tall waves -- but a launch of exactly one round ends when its slowest wave
+        // ends (the strips on the x faces take 1.5 times as long as the others, a wave that holds a source
+        // or a probe twice as long), and the short bands at the end of a launch only fill gaps if there
+        // are gaps to fill.  Measured over 3584^2 ... 8192 x 4096 (tools/roundscan.sh): rows x strips /
+        // (2048 x 1.45) is best or within 2 % of it (4096^2 435 Gcell-updates/s at 28 rows, 420 at 24, 419 at
+        // 32; 5632^2 561 at 44, 530 at 52, 524 at 40; 7168^2 633 at 72, 596 at 80, 594 at 64); from 9216^2 up,
+        // where 2048 waves saturate the memory system and the pass time follows the bytes, more and shorter
+        // waves balance the end of the launch better: 2.3 rounds, at most 176 rows (16384 x 8192: 750 at 120
+        // rows, 718 at 172; 9216^2 660 at 76, 674 at 88; 16384^2: 176 rows 790, 128 rows 775).
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
         const long work = (long)c->sn * strips;
-        long want = (work / 4800 + 8) / 16 * 16;
-        if (work < 500000)
-            want = work < 60000 ? 16 : work < 130000 ? 32 : work < 190000 ? 48 : work < 250000 ? 56 : work < 300000 ? 64 : work < 400000 ? 80 : 112;
-        c->tb_rows = (int)std::min(176L, std::max(16L, want));
+        const double rounds = work < 60000 ? 1.2 : work < 330000 ? 1.45 : 2.3;
+        const long want = (long)(work / (2048.0 * rounds) / 4.0 + 0.5) * 4;
+        c->tb_rows = (int)std::min(176L, std::max(8L, want));
         if ((double)c->nx * c->sn < 6e6) c->tb_rows = (int)std::max(4L, std::min((long)c->tb_rows, (long)c->sn * strips / 2048));
     }
     if (c->kernel == FDTD_KERNEL_MULTISTEP && c->sn != c->gn && c->sn < c->tb_steps) {
@@ -1680,6 +1713,31 @@ int fdtd_profile_read_launches(fdtd_ctx *c, float *sweep_ms, int32_t *steps, int
     return 0;
 }
 
+int fdtd_profile_waves_begin(fdtd_ctx *c, int64_t capacity)
+{
+    if (use_device(c)) return -10;
+    if (capacity > c->wave_trace_cap) {
+        if (c->wave_trace) (void)hipFree(c->wave_trace);
+        c->wave_trace = nullptr;
+        c->wave_trace_cap = 0;
+        HIPCHK(hipMalloc(&c->wave_trace, (size_t)capacity * 32));
+        c->wave_trace_cap = capacity;
+    }
+    c->wave_trace_n = 0;
+    c->wave_trace_armed = capacity > 0;
+    return 0;
+}
+
+int fdtd_profile_waves_read(fdtd_ctx *c, uint64_t *dst, int64_t capacity, int64_t *count)
+{
+    if (use_device(c)) return -10;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const long n = std::min<long>(capacity, c->wave_trace_n);
+    if (n > 0) HIPCHK(hipMemcpy(dst, c->wave_trace, (size_t)n * 32, hipMemcpyDeviceToHost));
+    if (count) *count = n;
+    return 0;
+}
+
 int fdtd_profile_read(fdtd_ctx *c, float *sweep_ms, int capacity, int *count)
 {
     return fdtd_profile_read_launches(c, sweep_ms, nullptr, capacity, count);
@@ -1718,12 +1776,15 @@ int fdtd_sweep_work(const fdtd_ctx *c, int64_t *waves, int64_t *row_iterations)
         return 0;
     }
     SweepTB a;
-    tb_rows_of(c, a, 0, c->sn);
-    const int64_t strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
     const int K = fdtd_steps_per_pass(c);
-    int64_t bands = a.big_bands, iters = 0;
-    for (int b = 0; b < a.big_bands; ++b) iters += std::min(a.rows, c->sn - b * a.rows) + 2 * K - 1;
-    for (int y = a.tail_begin; y < c->sn; y += a.tail_rows, ++bands) iters += std::min(a.tail_rows, c->sn - y) + 2 * K - 1;
+    tb_rows_of(c, a, 0, c->sn, K);
+    const int64_t strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
+    const int64_t bands = tb_band_count(a);
+    int64_t iters = 0;
+    for (int64_t b = 0; b < bands; ++b) {
+        int y0 = 0, y1 = 0;
+        if (tb_band_rows(a, b, y0, y1)) iters += y1 - y0 + 2 * K - 1;
+    }
     if (waves) *waves = bands * strips;
     if (row_iterations) *row_iterations = iters * strips;
     return 0;

@@ -120,6 +120,12 @@ struct SweepTB {
     // to another launch of the same pass).
     int y_begin, y_end, tail_begin;
     int big_bands, tail_rows;
+    // A launch that starts on the y = 0 face begins with one band of head_rows rows, one that ends on
+    // the y = ny-1 face ends with one of last_rows rows (0: none): the waves of those two bands run the
+    // fully guarded copy of the loop, about twice as slow as the others, and with 2K+1 and K+2 rows the
+    // bands next to them lie inside every y guard.  The big bands follow the head band, the tail bands
+    // stop last_rows short of y_end.
+    int head_rows, last_rows;
     // Waves that hold a source or a probe run the guarded copy of the loop for their whole band and
     // take about twice as long: started in the middle of a launch they finish after everybody else.
     // They go first: position i < nfirst of the launch does the work of wave first[i] (ascending), the
@@ -130,10 +136,58 @@ struct SweepTB {
     // faces of every band first (2 * band + side), the inner strips after them band by band.
     int faces_first;
     int strips;                           // waves across a row (kTbOwnWords owned words each)
+    unsigned long long *trace;            // diagnostics: per launch position {start, end, strip | band << 32, flags}, nullptr = off
     long long nwaves;                     // bands x strips (set by the launcher): positions of the padded last block beyond it leave
     int map;                              // 0: waves numbered band by band; 1: each XCD walks its own panel of strips
     int strips_per_xcd;                   // map 1: ceil(strips / 8)
 };
+
+#if defined(__HIP__) || defined(__HIPCC__)
+#define FDTD_HD __host__ __device__
+#else
+#define FDTD_HD
+#endif
+
+// Bands of a launch of the multi-step sweep, in order: head band, big bands, tail bands, last band.
+FDTD_HD inline long tb_band_count(const SweepTB &a)
+{
+    const int ye = a.y_end - a.last_rows;
+    const long tail = a.tail_begin < ye ? (ye - a.tail_begin + a.tail_rows - 1) / a.tail_rows : 0;
+    return (a.head_rows > 0 ? 1 : 0) + a.big_bands + tail + (a.last_rows > 0 ? 1 : 0);
+}
+
+// Rows [y0, y1) of band `band`; false past the last band.
+FDTD_HD inline bool tb_band_rows(const SweepTB &a, long band, int &y0, int &y1)
+{
+    const int ye = a.y_end - a.last_rows;
+    if (a.head_rows > 0) {
+        if (band == 0) {
+            y0 = a.y_begin;
+            y1 = a.y_begin + a.head_rows;
+            return true;
+        }
+        --band;
+    }
+    if (band < a.big_bands) {
+        y0 = a.y_begin + a.head_rows + (int)band * a.rows;
+        const int stop = a.tail_begin < ye ? a.tail_begin : ye;
+        y1 = y0 + a.rows < stop ? y0 + a.rows : stop;
+        return y0 < y1;
+    }
+    band -= a.big_bands;
+    const long tail = a.tail_begin < ye ? (ye - a.tail_begin + a.tail_rows - 1) / a.tail_rows : 0;
+    if (band < tail) {
+        y0 = a.tail_begin + (int)band * a.tail_rows;
+        y1 = y0 + a.tail_rows < ye ? y0 + a.tail_rows : ye;
+        return true;
+    }
+    if (band == tail && a.last_rows > 0) {
+        y0 = ye;
+        y1 = a.y_end;
+        return true;
+    }
+    return false;
+}
 
 // The tiled multi-step 2-D sweep (sweep2d_tile.hip): the arguments of a pass of the multi-step
 // sweep (b.rows, b.big_bands, b.tail_*, b.strips, b.map are not used; b.y_begin .. b.y_end are

@@ -96,6 +96,10 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     }
     const Grid2D &g = a.g;
     const int lane = threadIdx.x & 63;
+    // wave timeline (diagnostics, a.trace != nullptr): per launch position four words -- start and end
+    // on the 100 MHz clock, strip | band << 32, loop copy | hardware ids
+    const long trace_pos = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
+    const unsigned long long trace_t0 = a.trace ? wall_clock64() : 0ull;
     int strip, band;
     if (a.map == 0) {
         long wv = (long)blockIdx.x * WPB + (threadIdx.x >> 6);
@@ -139,12 +143,11 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         strip = (int)xcd * a.strips_per_xcd + (int)(q % a.strips_per_xcd);
         if (strip >= a.strips) return;
     }
-    // The first big_bands bands hold `rows` rows each, the bands after them tail_rows: short waves
-    // at the end of the launch keep the GPU full while the last long ones finish (3 % at 16384^2).
-    const bool big = band < a.big_bands;
-    const int y0 = big ? a.y_begin + band * a.rows : a.tail_begin + (band - a.big_bands) * a.tail_rows;
-    if (y0 >= a.y_end) return;
-    const int y1 = min(y0 + (big ? a.rows : a.tail_rows), a.y_end);
+    // Bands: a head band on the y = 0 face, big_bands bands of `rows` rows, bands of tail_rows rows
+    // (short waves at the end of the launch keep the GPU full while the last long ones finish: 3 % at
+    // 16384^2), a last band on the y = ny-1 face.
+    int y0, y1;
+    if (!tb_band_rows(a, band, y0, y1)) return;
     const int w = strip * OWN - LEFT + lane; // word of the row held by this lane
     const int x4 = w * 4;
     const bool act = w >= 0 && x4 < g.nx;
@@ -274,22 +277,26 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     };
 
     // Mur on the x faces of a freshly computed row (level s), fdtd_calculations.cu:369-395.
-    // Its field-independent factors of row r come from the per-row arrays; they are asked for before
-    // the stage that produces the row (mur_x_factors), so that the load is back when the stage is done.
-    auto mur_x_factors = [&](int r) -> f4 {
-        const int y = g.gy0 + r;
+    // Its field-independent factors come from the per-row arrays.  A wave holds one x face (grids
+    // narrower than a strip: both, see below); the factors of the K rows its stages work on wait in
+    // ONE register quadruple spread over the lanes -- lane l holds those of row j - l in iteration j,
+    // the entry of row j + 1 arrives with that row's loads and the queue moves up a lane per
+    // iteration --, and stage s takes its row's entry out of lane s - 1.  (A load per stage, as this
+    // was first written, made the strips on the x faces take twice as long as the others: the load
+    // had not arrived when the stage was done, and waiting for it waits for the next row's loads too.)
+    const bool face_x0 = w_first <= 0;              // the wave holds word 0
+    const bool face_both = face_x0 && wave_xe;      // grid of less than one strip: the x0 factors are loaded per stage
+    auto mur_x_row = [&](int j) -> f4 {             // the queue's entry for row j
+        const int y = g.gy0 + j;
         f4 cf = zero;
-        if (y >= 1 && y <= g.gny - 2) {
-            if (w == 0) cf = ((const f4 *)a.cfx0)[y];
-            if (wave_xe && w == xe_w) cf = ((const f4 *)a.cfxe)[y]; // (a grid of one word: the high face wins, as below)
-        }
+        if (y >= 1 && y <= g.gny - 2 && (face_x0 || wave_xe)) cf = ((const f4 *)(wave_xe ? a.cfxe : a.cfx0))[y];
         return cf;
     };
     auto mur_x = [&](f4 &et, const f4 &es, int r, const f4 &cf) {
         const int y = g.gy0 + r;
         const bool yok = y >= 1 && y <= g.gny - 2;
         if (w == 0 && yok) {
-            const f4 c0 = (wave_xe && w == xe_w) ? ((const f4 *)a.cfx0)[y] : cf;
+            const f4 c0 = face_both ? ((const f4 *)a.cfx0)[y] : cf;
             et.x = mur_apply(c0, et.y, es.y, es.x);
         }
         if (wave_xe) {
@@ -334,6 +341,7 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     // Everything a wave loads for one row (levels n, n-1 and H), and ez^n of the row above.
     struct RowIn {
         f4 hx, hy, ezp, dz, dzp, ezu;
+        f4 cfx; // x-face Mur factors of the row (waves on an x face only)
         unsigned cd;
     };
     auto ld4 = [&](const float *p) -> f4 { return PLAIN ? *(const f4 *)p : ld4_stream(p); };
@@ -348,6 +356,7 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         r.ezu = ld ? ld4(a.ez_n + off + pitch) : zero;
         // (a single material: no code is looked at)
         r.cd = (!ONE && ld) ? *(const unsigned *)(a.code + (long)(j + 1) * g.cpitch + x4) : 0u;
+        if (!decltype(mode)::inx) r.cfx = mur_x_row(j);
     };
 
     auto march = [&](auto mode) {
@@ -369,6 +378,7 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     RowIn cur;
     load(mode, cur, jlo);
     f4 ezc = (INX || act) ? ld4(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
+    float cfq[4] = {0.f, 0.f, 0.f, 0.f}; // the x-face Mur factors of rows j, j-1, ... in lanes 0, 1, ...
 
     for (int j = jlo; j <= jhi; ++j) {
         RowIn nxt;
@@ -376,6 +386,14 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         c[1].hx = cur.hx;
         c[1].dz = cur.dz;
         c[1].cd = cur.cd;
+        if (!INX) {
+            const float in_q[4] = {cur.cfx.x, cur.cfx.y, cur.cfx.z, cur.cfx.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float up = __shfl_up(cfq[i], 1);
+                cfq[i] = lane == 0 ? in_q[i] : up;
+            }
+        }
         f4 ezu = cur.ezu;
         // ez, dz of level s-1 and the new hy of the row stage s has just done: what stage s+1 needs
         // for that row in the next iteration.  They go into its slot once it has taken out this
@@ -403,15 +421,29 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
                     park(s - 2, 2) = pend_h;
                 }
             }
-            f4 cfx = zero;
-            if (!INX && s < K) cfx = mur_x_factors(r);
             StageOut o = stage(mode, c[s], hyin, ezp, dzp, ezu, s < K ? c[s < K ? s + 1 : s].hx : hx_top, r,
                                a.jz[s - 1]);
             // the next row's loads go out once stage 1 has consumed this row's registers
             if (s == 1 && j < jhi) load(mode, nxt, j + 1);
             if (s < K) {
                 const int y = g.gy0 + r;
-                if (!INX) mur_x(o.ez, c[s].ez, r, cfx);
+                if (!INX) {
+                    const f4 cfx = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfq[0]), s - 1)),
+                                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfq[1]), s - 1)),
+                                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfq[2]), s - 1)),
+                                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfq[3]), s - 1))};
+#ifdef FDTD_DEBUG_CFQ
+                    {
+                        const int y = g.gy0 + r;
+                        if (wave_xe && w == xe_w && y >= 1 && y <= g.gny - 2) {
+                            const f4 ref = ((const f4 *)a.cfxe)[y];
+                            if (ref.x != cfx.x || ref.y != cfx.y)
+                                printf("cfq mismatch band %d strip %d j %d s %d r %d: got %g %g want %g %g (lane %d)\n", band, strip, j, s, r, cfx.x, cfx.y, ref.x, ref.y, lane);
+                        }
+                    }
+#endif
+                    mur_x(o.ez, c[s].ez, r, cfx);
+                }
                 if (!INY && (y == g.gny - 1 || y == 1)) {
                     // ez of level s-1 of row r - 1 is parked in the slot of stage s + 1
                     const f4 below = park(s - 1, 0);
@@ -463,12 +495,20 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         march(LoopMode<false, true>{});
     else
         march(LoopMode<false, false>{});
+    if (a.trace && lane == 0) {
+        unsigned long long *t = a.trace + 4 * trace_pos;
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        t[0] = trace_t0;
+        t[1] = wall_clock64();
+        t[2] = (unsigned long long)(unsigned)strip | ((unsigned long long)(unsigned)band << 32);
+        t[3] = (unsigned long long)((inner_x ? 1u : 0u) | (inner_y ? 2u : 0u)) | ((unsigned long long)(xcc & 0xfu) << 8) |
+               ((unsigned long long)hw << 32);
+    }
 }
 
 template <int K> int launch_k(const SweepTB &a, hipStream_t stream)
 {
-    const long tail = a.tail_begin < a.y_end ? (a.y_end - a.tail_begin + a.tail_rows - 1) / a.tail_rows : 0;
-    const long bands = a.big_bands + tail;
+    const long bands = tb_band_count(a);
     if (bands <= 0) return 0;
     const bool one = a.ntab == 1;
     static const bool narrow = std::getenv("FDTD_TB_NARROW_TABLE") && std::atoi(std::getenv("FDTD_TB_NARROW_TABLE"));

@@ -190,6 +190,16 @@ int fdtd_profile_read(fdtd_ctx *ctx, float *sweep_ms, int capacity, int *count);
  * kernels; a pass of the multi-step sweep advances up to steps_per_pass, the
  * remainder pass of an fdtd_step() call fewer). */
 int fdtd_profile_read_launches(fdtd_ctx *ctx, float *sweep_ms, int32_t *steps, int capacity, int *count);
+/* Wave timeline of ONE launch of the multi-step 2-D sweep (diagnostics; no
+ * counterpart in the reference): fdtd_profile_waves_begin() arms it for the
+ * next pass with room for `capacity` waves, fdtd_profile_waves_read()
+ * synchronises and returns four 64-bit words per launch position: start and
+ * end of the wave on the GPU's constant 100 MHz clock, strip | band << 32,
+ * and flags (bit 0: x guards folded away, bit 1: y guards folded away, bits
+ * 8-11: XCC id, bits 32-63: the HW_ID register).  Positions of the padded last
+ * workgroup stay zero.  Other kernels record nothing (count = 0). */
+int fdtd_profile_waves_begin(fdtd_ctx *ctx, int64_t capacity);
+int fdtd_profile_waves_read(fdtd_ctx *ctx, uint64_t *dst, int64_t capacity, int64_t *count);
 /* Shape of one launch of the main sweep over the slab: the waves it starts and
  * the row iterations they execute in all (a wave of the multi-step sweep
  * marches its rows plus 2 * steps_per_pass - 1 rows around them; the one-step

@@ -282,6 +282,78 @@ def test_2d_multi_step_random_cases(oracle, seed, kind):
         assert util.compare(s, o, peak, f"seed {seed} nx {nx} ny {ny} K {k}") == 0
 
 
+@pytest.mark.parametrize("k", [2, 5, 8])
+@pytest.mark.parametrize("rows", [4, 9, 16])
+def test_2d_multi_step_short_bands_on_the_y_faces(oracle, monkeypatch, k, rows):
+    """Launches that touch a y face start with a band of 2K+1 rows and end with one of K+2 when the
+    grid is tall enough for it (2 * rows + 3K + 3 rows): grid heights on either side of that
+    threshold, band heights that do and do not divide the rest, Mur with random rp on all four
+    faces, tissue codes, sources and probes inside the two short bands, next to them and in the
+    x-face strips -- every field bit for bit against the oracle, probe series included."""
+    monkeypatch.setenv("FDTD_TB_ROWS", str(rows))
+    limit = 2 * rows + 3 * k + 3
+    for ny in (limit - 1, limit, limit + 7, 4 * limit + 3):
+        nx = 487                                   # three strips: both x faces and a plain one
+        rng = np.random.default_rng(7000 + 31 * ny + k)
+        srcs = [(1, 1, 0), (nx - 1, ny - 1, 0), (nx // 2, 2 * k, 0), (nx // 2 + 1, 2 * k + 1, 0), (250, ny - k - 2, 0),
+                (3, ny - k - 3, 0)]
+        s, o = util.pair(oracle, (nx, ny, 1), srcs, CON, kernel=(B.KERNEL_MULTISTEP, k), sigma=0.2, eps_s=9.0, eps_i=3.0,
+                         tau_d=2e-11)
+        util.set_materials(s, o, rng.integers(0, len(util.RIKEN_LIKE), size=(1, ny, nx), dtype=np.uint8))
+        for face in (0, 1, 3, 4):
+            rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+            s.set_rp(face, rp)
+            o.set_rp(face, rp)
+        util.randomize(s, o, rng, oracle)
+        probes = [(0, 0, 0), (nx - 1, ny - 1, 0), (nx // 2, 2 * k, 0), (241, 2 * k + 1, 0), (5, ny - k - 2, 0), (nx - 2, ny - k - 3, 0)]
+        steps = 2 * k + 3                          # two full passes and a remainder pass
+        s.set_probes(probes, capacity=steps)
+        want = []
+        peak = util.Peak()
+        for _ in range(steps):
+            o.step(1)
+            peak.update(o, util.fields_of(s))
+            want.append([[float(np.asarray(o.field(f)).reshape(ny, nx)[y, x]) for f in (B.HX, B.HY, B.DZ, B.EZ)] for x, y, _ in probes])
+        s.step(steps)
+        assert util.compare(s, o, peak, f"short face bands K {k} rows {rows} ny {ny}") == 0
+        got = s.read_probes(0, steps)
+        assert np.array_equal(got.view(np.uint32), np.asarray(want, dtype=np.float32).view(np.uint32)), (k, rows, ny)
+        s.close()
+
+
+def test_wave_timeline_of_a_multi_step_pass():
+    """fdtd_profile_waves_*: one record per wave of the next pass -- every wave of the launch is
+    there once, its clock readings are ordered and lie inside the launch, the strips and bands
+    cover the grid, and the run is unchanged by it."""
+    nx, ny, k = 2000, 700, 8
+    a = fdtd_amd.Solver(fdtd_amd.make_params(nx, ny, 1, [(1000, 350, 0)]), ecoef=CON, kernel=(B.KERNEL_MULTISTEP, k))
+    b = fdtd_amd.Solver(fdtd_amd.make_params(nx, ny, 1, [(1000, 350, 0)]), ecoef=CON, kernel=(B.KERNEL_MULTISTEP, k))
+    a.step(3 * k)
+    b.step(3 * k)
+    waves, _ = a.sweep_work
+    a.profile_begin(1)
+    a.profile_waves_begin(waves + 8)
+    a.step(k)
+    b.step(k)
+    ms, _ = a.profile_read_launches(1)
+    t = a.profile_waves_read(waves + 8)
+    t = t[t[:, 1] > 0]
+    assert len(t) == waves
+    start, end = t[:, 0].astype(np.int64), t[:, 1].astype(np.int64)
+    assert (end > start).all()
+    assert (end.max() - start.min()) * 1e-5 <= ms[0] * 1.05 + 0.02          # 100 MHz ticks -> ms
+    strips = (t[:, 2] & np.uint64(0xffffffff)).astype(int)
+    bands = (t[:, 2] >> np.uint64(32)).astype(int)
+    assert strips.min() == 0 and strips.max() == (nx // 4 + 59) // 60 - 1
+    assert len(set(zip(strips.tolist(), bands.tolist()))) == waves          # every (strip, band) once
+    flags = (t[:, 3] & np.uint64(3)).astype(int)
+    assert (flags == 3).any() and (flags != 3).any()                        # plain waves and guarded ones
+    a.step(k)                                                               # the next pass records nothing
+    b.step(k)
+    for f in (B.HX, B.HY, B.DZ, B.EZ):
+        assert np.array_equal(a.field(f).view(np.uint32), b.field(f).view(np.uint32))
+
+
 # ------------------------------------------------------------------ slabs
 
 @pytest.mark.parametrize("kernel", KERNELS)

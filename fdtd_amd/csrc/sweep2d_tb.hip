@@ -253,26 +253,27 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
             o.dz[i] = dn;
         }
 
+        // (the new value is computed for every cell and the guard picks: written as `guard ? update :
+        // old` the compiler branches around each cell's fp64 chain, and the four chains of a lane, no
+        // longer interleaved, take the strips on the x faces half as long again as the others)
+        f4 en;
         if (!ONE && WIDE) {
             if (words_uniform) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? e_update_wide(mu, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
-                                                         : ezp[i];
+                for (int i = 0; i < 4; ++i) en[i] = e_update_wide(mu, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const MatCoef mi = tabw[(in.cd >> (8 * i)) & 0xffu];
-                    o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? e_update_wide(mi, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
-                                                         : ezp[i];
+                    en[i] = e_update_wide(mi, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
                 }
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
-                                                     : ezp[i];
+            for (int i = 0; i < 4; ++i) en[i] = e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? en[i] : ezp[i];
         return o;
     };
 
@@ -287,27 +288,38 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     const bool face_x0 = w_first <= 0;              // the wave holds word 0
     const bool face_both = face_x0 && wave_xe;      // grid of less than one strip: the x0 factors are loaded per stage
     auto mur_x_row = [&](int j) -> f4 {             // the queue's entry for row j
-        const int y = g.gy0 + j;
-        f4 cf = zero;
-        if (y >= 1 && y <= g.gny - 2 && (face_x0 || wave_xe)) cf = ((const f4 *)(wave_xe ? a.cfxe : a.cfx0))[y];
-        return cf;
+        // (rows outside 1 .. gny-2 take no Mur update and a wave without a face uses none: any entry
+        // the slab holds will do, and an unconditional load needs no wait where a branch would join)
+        const int y = min(max(g.gy0 + j, 1), g.gny - 2);
+        return ((const f4 *)(wave_xe ? a.cfxe : a.cfx0))[y];
     };
+    // (Every lane evaluates the face formula and the face lane takes the result: a select costs less
+    // than a divergent branch per stage, and the cell next to x = nx-1 sits in the same word unless
+    // nx = 4m + 1, so the two lane exchanges are rarely needed.)
     auto mur_x = [&](f4 &et, const f4 &es, int r, const f4 &cf) {
         const int y = g.gy0 + r;
         const bool yok = y >= 1 && y <= g.gny - 2;
-        if (w == 0 && yok) {
-            const f4 c0 = face_both ? ((const f4 *)a.cfx0)[y] : cf;
-            et.x = mur_apply(c0, et.y, es.y, es.x);
+        if (face_x0) {
+            f4 c0 = cf;
+            if (face_both) c0 = ((const f4 *)a.cfx0)[min(max(y, 1), g.gny - 2)];
+            const float v = mur_apply(c0, et.y, es.y, es.x);
+            et.x = (w == 0 && yok) ? v : et.x;
         }
         if (wave_xe) {
-            const float t_prev = __shfl_up(et.w, 1), s_prev = __shfl_up(es.w, 1);
-            if (w == xe_w && yok) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (i == xe_c) {
-                        const float t_in = i ? et[i ? i - 1 : 0] : t_prev, s_in = i ? es[i ? i - 1 : 0] : s_prev;
-                        et[i] = mur_apply(cf, t_in, s_in, es[i]);
-                    }
+            const bool on = w == xe_w && yok;
+            if (xe_c == 0) {
+                const float t_prev = __shfl_up(et.w, 1), s_prev = __shfl_up(es.w, 1);
+                const float v = mur_apply(cf, t_prev, s_prev, es.x);
+                et.x = on ? v : et.x;
+            } else if (xe_c == 1) {
+                const float v = mur_apply(cf, et.x, es.x, es.y);
+                et.y = on ? v : et.y;
+            } else if (xe_c == 2) {
+                const float v = mur_apply(cf, et.y, es.y, es.z);
+                et.z = on ? v : et.z;
+            } else {
+                const float v = mur_apply(cf, et.z, es.z, es.w);
+                et.w = on ? v : et.w;
             }
         }
     };
@@ -345,17 +357,22 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         unsigned cd;
     };
     auto ld4 = [&](const float *p) -> f4 { return PLAIN ? *(const f4 *)p : ld4_stream(p); };
+    // Lanes outside the row (left of word 0, right of the last word) load the nearest word of the row
+    // instead of nothing: what they hold is never stored and never reaches a cell inside the grid (the
+    // x guards of the updates keep the cells at x = 0 and x = nx-1 from reading beyond them), and loads
+    // without a predicate are not waited for one by one.
+    const int x4l = act ? x4 : w < 0 ? 0 : ((g.nx - 1) >> 2) << 2;
     auto load = [&](auto mode, RowIn &r, int j) {
-        const bool ld = decltype(mode)::inx || act;
-        const long off = (long)(j + 1) * pitch + x4;
-        r.hx = ld ? ld4(a.hx_r + off) : zero;
-        r.hy = ld ? ld4(a.hy_r + off) : zero;
-        r.ezp = ld ? ld4(a.ez_p + off) : zero;
-        r.dz = ld ? ld4(a.dz_n + off) : zero;
-        r.dzp = ld ? ld4(a.dz_p + off) : zero;
-        r.ezu = ld ? ld4(a.ez_n + off + pitch) : zero;
+        const int xc = decltype(mode)::inx ? x4 : x4l;
+        const long off = (long)(j + 1) * pitch + xc;
+        r.hx = ld4(a.hx_r + off);
+        r.hy = ld4(a.hy_r + off);
+        r.ezp = ld4(a.ez_p + off);
+        r.dz = ld4(a.dz_n + off);
+        r.dzp = ld4(a.dz_p + off);
+        r.ezu = ld4(a.ez_n + off + pitch);
         // (a single material: no code is looked at)
-        r.cd = (!ONE && ld) ? *(const unsigned *)(a.code + (long)(j + 1) * g.cpitch + x4) : 0u;
+        r.cd = !ONE ? *(const unsigned *)(a.code + (long)(j + 1) * g.cpitch + xc) : 0u;
         if (!decltype(mode)::inx) r.cfx = mur_x_row(j);
     };
 
@@ -377,7 +394,7 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     }
     RowIn cur;
     load(mode, cur, jlo);
-    f4 ezc = (INX || act) ? ld4(a.ez_n + (long)(jlo + 1) * pitch + x4) : zero;
+    f4 ezc = ld4(a.ez_n + (long)(jlo + 1) * pitch + (INX ? x4 : x4l));
     float cfq[4] = {0.f, 0.f, 0.f, 0.f}; // the x-face Mur factors of rows j, j-1, ... in lanes 0, 1, ...
 
     for (int j = jlo; j <= jhi; ++j) {

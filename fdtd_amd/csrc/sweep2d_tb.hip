@@ -262,10 +262,15 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
 #pragma unroll
                 for (int i = 0; i < 4; ++i) en[i] = e_update_wide(mu, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
             } else {
+                // (a word with several materials: a table row of twelve registers per cell, taken when
+                // the cell's turn comes -- all four at once do not fit beside the state of the march)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const MatCoef mi = tabw[(in.cd >> (8 * i)) & 0xffu];
-                    en[i] = e_update_wide(mi, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
+                    en[i] = ezp[i];
+                    if ((INY || gy_ez) && (INX || m_ez[i])) {
+                        const MatCoef mi = tabw[(in.cd >> (8 * i)) & 0xffu];
+                        en[i] = e_update_wide(mi, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
+                    }
                 }
             }
         } else {

@@ -147,6 +147,81 @@ def test_3d_body_slices_at_full_plane_size(oracle, kernel):
     assert util.run_and_compare(s, o, steps, 5, "3-D body slices") == 0
     assert np.abs(s.field(B.EX)).max() > 0
 
+@pytest.mark.timeout(900)
+def test_3d_whole_body_model_265x490x1687_every_cell(oracle, capsys):
+    """The workload the reference's data was made for, at its full size: all 1687 slices of the voxel
+    body model (tests/golden/body_codes_265x490x1687.u8.xz -- the codes of the reference's PGM files,
+    53 tissues), mat_specs_riken, rp planes from the loaded materials, a random state in every
+    cell inside the outermost layer at both time levels (the cells no kernel ever writes lie on the
+    faces and stay zero, as in the reference), sources in air and in tissue.  Four steps (every phase
+    of the reference's three-buffer rotation and two source samples): all nine fields of all
+    219 M cells against the oracle bit for bit.  About a minute, most of it host-side set-up: it
+    says where it is (a silent minute looks like a hang to a watchdog)."""
+    import gc
+    import lzma
+    import time
+    import psutil
+    t_start = time.time()
+
+    def say(what):
+        with capsys.disabled():
+            print(f"[whole body model, {time.time() - t_start:5.1f} s] {what}", flush=True)
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "body_codes_265x490x1687.u8.xz")
+    if psutil.virtual_memory().available < 50e9:
+        pytest.skip("needs 50 GB of host memory (the oracle's state is 22 GB)")
+    nx, ny, nz, steps = 265, 490, 1687, 4
+    n = nx * ny * nz
+    codes = np.frombuffer(lzma.decompress(open(path, "rb").read()), dtype=np.uint8).reshape(nz, ny, nx)
+    base = B.read_pgm_codes(os.path.join(DATA, "pgmdata", "v1_00800.pgm"), nx, ny)
+    assert np.array_equal(codes[799], base)                     # slice 800 is the shipped PGM file
+    srcs = [(40, 245, 800), (132, 245, 900), (1, 1, 0), (264, 489, 1686)]
+    s, o = util.pair(oracle, (nx, ny, nz), srcs, CON)
+    assert s.sweep_kernel_name == "fdtd3d_sweep"
+    table, present = B.read_material_specs(os.path.join(DATA, "mat_specs_riken"))
+    assert set(np.unique(codes).tolist()) <= set(np.flatnonzero(present).tolist())
+    for code in np.flatnonzero(present):
+        s.set_material(int(code), *[float(v) for v in table[code]])
+    s.set_codes(codes)
+    o.set_materials(codes, table)
+    say("materials set")
+    s.setup_mur_from_materials()
+    o.setup_mur()
+    for face in range(6):
+        assert np.array_equal(s.rp(face), o.rp(face)), face
+    rng = np.random.default_rng(2024)
+    stride = 1000003
+    noise = rng.standard_normal(n + 16 * stride, dtype=np.float32)
+    i = 0
+    for fid in range(9):
+        for lvl in ((0,) if fid <= B.HZ else (0, 1)):
+            i += 1
+            amp = np.float32(1e-12 if B.DX <= fid <= B.DZ else (1e-3 if fid <= B.HZ else 1.0))
+            data = (noise[i * stride:i * stride + n] * amp).reshape(nz, ny, nx)
+            if fid > B.HZ:
+                data[0] = data[-1] = 0.0
+                data[:, 0] = data[:, -1] = 0.0
+                data[:, :, 0] = data[:, :, -1] = 0.0
+            s.set_field(fid, data, lvl)
+            o.set_field(fid, data, lvl)
+        say(f"state of {B.FIELD_NAMES[fid]} set")
+    del noise, data
+    gc.collect()
+    o.step(steps, threads=16)
+    say("oracle stepped")
+    s.step(steps)
+    s.sync()
+    say("GPU stepped")
+    for fid in range(9):
+        got, want = s.field(fid), np.asarray(o.field(fid))
+        assert np.isfinite(want).all() and np.count_nonzero(want) > 0.8 * want.size
+        util.assert_bits_equal(got, want, f"whole body model, {B.FIELD_NAMES[fid]}")
+        del got
+        say(f"{B.FIELD_NAMES[fid]} equal")
+    s.close()
+    o.close()
+
+
 # ------------------------------------------------------------------ 2-D TMz
 
 MS2, MS3, MS4, MS5, MS6, MS7, MS8 = [(B.KERNEL_MULTISTEP, k) for k in (2, 3, 4, 5, 6, 7, 8)]

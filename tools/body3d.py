@@ -1,5 +1,5 @@
-"""Step time of the 3-D sweep on the full body model (265 x 490 x 1687, mat_specs_riken; the PGM
-slice v1_00800 stands in for every z: only one slice is shipped) and on 512^3 vacuum."""
+"""Step time of the 3-D sweep on the full body model (265 x 490 x 1687, mat_specs_riken, the codes of all
+1687 slices from tests/golden/body_codes_265x490x1687.u8.xz) and on 512^3 vacuum."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -14,8 +14,10 @@ def run(dims, body, steps=60):
         table, _ = B.read_material_specs(os.path.join(DATA, "mat_specs_riken"))
         for code, row in enumerate(table):
             s.set_material(code, *[float(v) for v in row])
-        codes = B.read_pgm_codes(os.path.join(DATA, "pgmdata", "v1_00800.pgm"), 265, 490)
-        s.set_codes(np.broadcast_to(codes, (nz, ny, nx)).copy())
+        import lzma
+        path = os.path.join(DATA, "..", "tests", "golden", "body_codes_265x490x1687.u8.xz")
+        s.set_codes(np.frombuffer(lzma.decompress(open(path, "rb").read()), dtype=np.uint8).reshape(nz, ny, nx))
+        s.setup_mur_from_materials()
     s.step(10); s.sync()
     s.profile_begin(steps)
     t0 = time.perf_counter(); s.step(steps); s.sync(); el = time.perf_counter() - t0

@@ -52,6 +52,11 @@ __device__ __forceinline__ f4 shift_right(f4 v, int lane, float edge)
     return r;
 }
 
+#ifndef FDTD_3D_LDS_TABLE
+#define FDTD_3D_LDS_TABLE 1
+#endif
+constexpr bool LDS_TABLE = FDTD_3D_LDS_TABLE != 0;
+
 // FLAT: the segment space is all planes of the launch (small grids), not one plane.
 template <bool ONE, int W, bool MUR, bool FLAT> __global__ __launch_bounds__(256, W) void fdtd3d_sweep(const Fused3D a)
 {
@@ -75,6 +80,13 @@ template <bool ONE, int W, bool MUR, bool FLAT> __global__ __launch_bounds__(256
         }
         return;
     }
+    // Grids with several materials: the coefficient table goes into LDS (4 KB per workgroup, one row
+    // per thread, asked for before every other load; the barrier sits in front of the E update).  On
+    // the body model three waves of five hold more than one tissue -- a row of 265 cells that crosses
+    // the body -- and gathered their four rows per lane from memory at the very end of the thread.
+    __shared__ MatEntry tab[ONE ? 1 : FDTD_MAX_CODES];
+    if (!ONE && LDS_TABLE)
+        for (int i = threadIdx.x; i < FDTD_MAX_CODES; i += blockDim.x) tab[i] = a.table[i];
     // Block ids are dealt to the 8 XCDs in turn.  XCD i (block id mod 8) owns segment i --
     // one eighth of the words -- of EVERY plane and walks the planes in z order, so the
     // lines of plane z-1 and z+1 it needs are the ones it pulled into its own L2 a plane ago.
@@ -255,11 +267,12 @@ template <bool ONE, int W, bool MUR, bool FLAT> __global__ __launch_bounds__(256
     }
 
     // E, fdtd_calculations.cu:147-182
+    if (!ONE && LDS_TABLE) __syncthreads();
     f4 en[3];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         MatEntry m = mu;
-        if (!ONE && !uniform) m = a.table[(cd >> (8 * i)) & 0xffu];
+        if (!ONE && !uniform) m = LDS_TABLE ? tab[(cd >> (8 * i)) & 0xffu] : a.table[(cd >> (8 * i)) & 0xffu];
         const bool g_ex = x_hi[i] && y_lo && y_hi && z_lo && z_hi;
         const bool g_eyz = x_lo[i] && z_lo;
         en[0][i] = g_ex ? e_update(m, g.dt, ex_c[i], e1[0][i], dn[0][i], d0[0][i], d1[0][i]) : e1[0][i];

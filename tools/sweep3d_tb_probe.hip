@@ -165,14 +165,18 @@ struct V3 {
     f4 x, y, z;
 };
 
-// NT: stores with the nontemporal hint; PREFETCH: the next plane's loads before stage 2 instead of after it
-template <bool NT, bool PREFETCH> __global__ __launch_bounds__(TX *TY, 2) void sweep3d_two(const Pass a)
+// NT: stores with the nontemporal hint.  PREFETCH 1: the next plane's loads before stage 2 instead of after it
+// (256 registers, spills).  PREFETCH 2: only what stage 1 needs first (H, the E plane above, the y+1 words)
+// before stage 2, the rest at the top of the iteration, and E^n, D^n of the plane stage 2 works on parked in
+// LDS (48 KB more) to make room.
+template <bool NT, int PREFETCH> __global__ __launch_bounds__(TX *TY, 2) void sweep3d_two(const Pass a)
 {
     const Grid &g = a.g;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     __shared__ f4 ex1[2][TX * TY]; // stage 1: new hz, hx of the plane (for the thread above)
     __shared__ f4 ex2[2][TX * TY]; // E^n+1 ez, ex of the plane stage 1 did last (for the thread below)
     __shared__ f4 ex3[2][TX * TY]; // stage 2: new hz, hx
+    __shared__ f4 parkq[PREFETCH == 2 ? 6 : 1][TX * TY]; // E^n, D^n of plane p-1 (own slots: no barrier)
 
     const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid / TX;
     // blocks: tile index fastest within a segment, so that neighbouring tiles run at the same time
@@ -217,14 +221,23 @@ template <bool NT, bool PREFETCH> __global__ __launch_bounds__(TX *TY, 2) void s
         V3 h_n, e_up, e_pr, d_n, d_pr;
         f4 ez_y1, ex_y1;
     };
-    auto load = [&](In &in, int p) {
-        in.h_n = ld3(a.h_r, p), in.e_up = ld3(a.e0, p + 1), in.e_pr = ld3(a.e1, p), in.d_n = ld3(a.d0, p), in.d_pr = ld3(a.d1, p);
+    auto load_a = [&](In &in, int p) {
+        in.h_n = ld3(a.h_r, p), in.e_up = ld3(a.e0, p + 1);
         in.ez_y1 = ld(a.e0, p, y + 1, 2, up_ok), in.ex_y1 = ld(a.e0, p, y + 1, 0, up_ok);
     };
+    auto load_b = [&](In &in, int p) { in.e_pr = ld3(a.e1, p), in.d_n = ld3(a.d0, p), in.d_pr = ld3(a.d1, p); };
+    auto load = [&](In &in, int p) {
+        load_a(in, p);
+        load_b(in, p);
+    };
     In cur;
-    load(cur, z0 - 2);
+    if (PREFETCH == 2)
+        load_a(cur, z0 - 2);
+    else
+        load(cur, z0 - 2);
 
     for (int p = z0 - 2; p <= z1; ++p) {
+        if (PREFETCH == 2) load_b(cur, p);
         // ---- stage 1 on plane p ----
         V3 h1;
         h1.x = upd_hx(g, cur.h_n.x, e_cur.z, cur.ez_y1, e_cur.y, cur.e_up.y);
@@ -248,7 +261,8 @@ template <bool NT, bool PREFETCH> __global__ __launch_bounds__(TX *TY, 2) void s
         const V3 e_n = e_cur, d_n = cur.d_n;
         e_cur = cur.e_up;
         // the next plane's loads go out now: stage 2 below runs while they are in flight
-        if (PREFETCH && p < z1) load(cur, p + 1);
+        if (PREFETCH == 1 && p < z1) load(cur, p + 1);
+        if (PREFETCH == 2 && p < z1) load_a(cur, p + 1);
 
         // ---- stage 2 on plane p-1 ----
         V3 h2;
@@ -260,6 +274,10 @@ template <bool NT, bool PREFETCH> __global__ __launch_bounds__(TX *TY, 2) void s
         __syncthreads();
         const f4 hz2_ym = ex3[0][dn], hx2_ym = ex3[1][dn];
         V3 d2, e2;
+        if (PREFETCH == 2) {
+            s_en.x = parkq[0][tid], s_en.y = parkq[1][tid], s_en.z = parkq[2][tid];
+            s_dn.x = parkq[3][tid], s_dn.y = parkq[4][tid], s_dn.z = parkq[5][tid];
+        }
         d2.x = upd_dx(g, s_d1.x, h2.z, hz2_ym, h2.y, hy2_zm);
         d2.y = upd_dy(g, s_d1.y, h2.x, hx2_zm, h2.z, xm(h2.z));
         d2.z = upd_dz(g, s_d1.z, h2.y, xm(h2.y), h2.x, hx2_ym);
@@ -282,8 +300,14 @@ template <bool NT, bool PREFETCH> __global__ __launch_bounds__(TX *TY, 2) void s
             st(a.d_a, 0, s_d1.x), st(a.d_a, 1, s_d1.y), st(a.d_a, 2, s_d1.z);
         }
         hx2_zm = h2.x, hy2_zm = h2.y;
-        s_e1 = e1, s_h1 = h1, s_d1 = d1, s_en = e_n, s_dn = d_n;
-        if (!PREFETCH && p < z1) load(cur, p + 1);
+        s_e1 = e1, s_h1 = h1, s_d1 = d1;
+        if (PREFETCH == 2) {
+            parkq[0][tid] = e_n.x, parkq[1][tid] = e_n.y, parkq[2][tid] = e_n.z;
+            parkq[3][tid] = d_n.x, parkq[4][tid] = d_n.y, parkq[5][tid] = d_n.z;
+        } else {
+            s_en = e_n, s_dn = d_n;
+        }
+        if (PREFETCH == 0 && p < z1) load(cur, p + 1);
     }
 }
 
@@ -368,14 +392,18 @@ int main(int argc, char **argv)
     printf("two-step sweep: %d x %d tiles x %d segments = %u workgroups of %d threads; owned share of the word slots %.3f\n", a.tiles_x,
            a.tiles_y, segs, sg.x, TX * TY, (double)g.roww * g.ny / ((double)a.tiles_x * a.tiles_y * TX * TY));
     const bool nt = getenv("PROBE_NT") && atoi(getenv("PROBE_NT"));
-    const bool pf = !getenv("PROBE_PREFETCH") || atoi(getenv("PROBE_PREFETCH"));
+    const int pf = getenv("PROBE_PREFETCH") ? atoi(getenv("PROBE_PREFETCH")) : 0;
     auto sweep = [&]() {
-        if (nt)
-            hipLaunchKernelGGL((sweep3d_two<true, false>), sg, sb, 0, 0, a);
-        else if (pf)
-            hipLaunchKernelGGL((sweep3d_two<false, true>), sg, sb, 0, 0, a);
+        if (nt && pf == 2)
+            hipLaunchKernelGGL((sweep3d_two<true, 2>), sg, sb, 0, 0, a);
+        else if (nt)
+            hipLaunchKernelGGL((sweep3d_two<true, 0>), sg, sb, 0, 0, a);
+        else if (pf == 2)
+            hipLaunchKernelGGL((sweep3d_two<false, 2>), sg, sb, 0, 0, a);
+        else if (pf == 1)
+            hipLaunchKernelGGL((sweep3d_two<false, 1>), sg, sb, 0, 0, a);
         else
-            hipLaunchKernelGGL((sweep3d_two<false, false>), sg, sb, 0, 0, a);
+            hipLaunchKernelGGL((sweep3d_two<false, 0>), sg, sb, 0, 0, a);
     };
     sweep();
     CHK(hipDeviceSynchronize());

@@ -21,7 +21,7 @@ seen = []
 for a, b in sorted(loops, key=lambda t: t[1] - t[0]):
     seg = body[a:b + 1]
     cnt = lambda pat: sum(1 for l in seg if re.match(r'\s+' + pat, l))
-    if cnt('global_store') != 6 or any(a >= x and b <= y for x, y in seen):
+    if cnt('global_store') < 6 or any(a >= x and b <= y for x, y in seen):
         continue
     if any(x >= a and y <= b for x, y in seen):
         continue

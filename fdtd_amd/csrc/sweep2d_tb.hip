@@ -37,6 +37,7 @@
 // stored as the E update leaves it; the ordinary Mur kernel finishes it.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "device_math.h"
 
@@ -56,6 +57,12 @@ struct StageOut {
     f4 ez, hx, hy, dz;
 };
 
+// f(integral_constant<int, 1>), f(integral_constant<int, 2>), ... one call per element of the sequence
+template <int... N, class F> __device__ __forceinline__ void for_each_count(std::integer_sequence<int, N...>, F &&f)
+{
+    (f(std::integral_constant<int, N + 1>{}), ...);
+}
+
 // Which guards a copy of the marching loop folds away at compile time.
 template <bool INX, bool INY> struct LoopMode {
     static constexpr bool inx = INX, iny = INY;
@@ -65,6 +72,12 @@ template <bool INX, bool INY> struct LoopMode {
 // rows per wave plus the 4 KB table allow three (two workgroups per CU either way).  The 48-byte-row
 // variant holds at most kWideTableRowsK8 rows there and keeps one more hy row in registers, which
 // leaves room for four waves: 2 x (4 x 19 KB + 4 KB) = 160 KB.
+#ifndef FDTD_TB_SKIP_FILL
+#define FDTD_TB_SKIP_FILL 1
+#endif
+#ifndef FDTD_TB_UNROLL2
+#define FDTD_TB_UNROLL2 0
+#endif
 #ifndef FDTD_TB8_TABLE_WAVES
 #define FDTD_TB8_TABLE_WAVES 3
 #endif
@@ -146,6 +159,10 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     // Bands: a head band on the y = 0 face, big_bands bands of `rows` rows, bands of tail_rows rows
     // (short waves at the end of the launch keep the GPU full while the last long ones finish: 3 % at
     // 16384^2), a last band on the y = ny-1 face.
+    // (one strip and one band per wave: said out loud, the row arithmetic, the guards in y and the
+    // row part of every address go to the scalar unit)
+    strip = __builtin_amdgcn_readfirstlane(strip);
+    band = __builtin_amdgcn_readfirstlane(band);
     int y0, y1;
     if (!tb_band_rows(a, band, y0, y1)) return;
     const int w = strip * OWN - LEFT + lane; // word of the row held by this lane
@@ -184,6 +201,7 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     }
 
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const OneCoef onec = one_coef(a.one, g.dt); // (used by the single-material variants only)
 
     // LDS: per wave and stage s >= 2 one slot {ez, dz of level s-2, hy of level s-1} for the row
     // stage s works on next; every lane reads and writes its own 16 bytes, no other wave touches
@@ -275,7 +293,9 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) en[i] = e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
+            for (int i = 0; i < 4; ++i)
+                en[i] = ONE ? e_update_one(onec, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i])
+                            : e_update(m[i], g.dt, in.ez[i], ezp[i], o.dz[i], in.dz[i], dzp[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) o.ez[i] = ((INY || gy_ez) && (INX || m_ez[i])) ? en[i] : ezp[i];
@@ -368,16 +388,24 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     // without a predicate are not waited for one by one.
     const int x4l = act ? x4 : w < 0 ? 0 : ((g.nx - 1) >> 2) << 2;
     auto load = [&](auto mode, RowIn &r, int j) {
-        const int xc = decltype(mode)::inx ? x4 : x4l;
-        const long off = (long)(j + 1) * pitch + xc;
-        r.hx = ld4(a.hx_r + off);
-        r.hy = ld4(a.hy_r + off);
-        r.ezp = ld4(a.ez_p + off);
-        r.dz = ld4(a.dz_n + off);
-        r.dzp = ld4(a.dz_p + off);
-        r.ezu = ld4(a.ez_n + off + pitch);
+        // (the row's address in scalar registers, the lane's 32-bit byte offset beside it)
+        const unsigned xb = 4u * (unsigned)(decltype(mode)::inx ? x4 : x4l);
+        const long off = (long)(j + 1) * pitch;
+        // (the empty asm keeps the compiler from folding the lane offset into twelve per-lane base
+        // addresses that it then holds in 24 registers across the loop)
+        auto at = [&](const float *row) {
+            unsigned long long u = (unsigned long long)row;
+            asm volatile("" : "+s"(u));
+            return (const float *)((const __attribute__((address_space(1))) char *)u + xb);
+        };
+        r.hx = ld4(at(a.hx_r + off));
+        r.hy = ld4(at(a.hy_r + off));
+        r.ezp = ld4(at(a.ez_p + off));
+        r.dz = ld4(at(a.dz_n + off));
+        r.dzp = ld4(at(a.dz_p + off));
+        r.ezu = ld4(at(a.ez_n + off + pitch));
         // (a single material: no code is looked at)
-        r.cd = !ONE ? *(const unsigned *)(a.code + (long)(j + 1) * g.cpitch + xc) : 0u;
+        r.cd = !ONE ? *(const unsigned *)(a.code + (long)(j + 1) * g.cpitch + (xb >> 2)) : 0u;
         if (!decltype(mode)::inx) r.cfx = mur_x_row(j);
     };
 
@@ -402,7 +430,9 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
     f4 ezc = ld4(a.ez_n + (long)(jlo + 1) * pitch + (INX ? x4 : x4l));
     float cfq[4] = {0.f, 0.f, 0.f, 0.f}; // the x-face Mur factors of rows j, j-1, ... in lanes 0, 1, ...
 
-    for (int j = jlo; j <= jhi; ++j) {
+    // One iteration of the march with the first NACT stages at work.
+    auto iterate = [&](auto nact_c, int j) {
+        constexpr int NACT = decltype(nact_c)::value;
         RowIn nxt;
         c[1].ez = ezc;
         c[1].hx = cur.hx;
@@ -424,6 +454,10 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         Level keep[K + 1];
 #pragma unroll
         for (int s = 1; s <= K; ++s) {
+            if (s > NACT) {
+                if (s < K) keep[s + 1] = c[s + 1];
+                continue;
+            }
             const int r = j - (s - 1);
             f4 ezp, dzp, hyin;
             if (s == 1) {
@@ -485,13 +519,19 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
                 pend_d = c[s].dz;
                 pend_h = o.hy;
             } else if (own && r >= y0 && r < y1) {
-                const long q = (long)(r + 1) * pitch + x4;
-                st4_stream(a.hx_w + q, o.hx);
-                st4_stream(a.hy_w + q, o.hy);
-                st4_stream(a.dz_b + q, o.dz);
-                st4_stream(a.ez_b + q, o.ez);
-                st4_stream(a.dz_a + q, c[K].dz);
-                st4_stream(a.ez_a + q, c[K].ez);
+                const long q = (long)(r + 1) * pitch;
+                const unsigned xb = 4u * (unsigned)x4;
+                auto at = [&](float *row) {
+                    unsigned long long u = (unsigned long long)row;
+                    asm volatile("" : "+s"(u));
+                    return (float *)((__attribute__((address_space(1))) char *)u + xb);
+                };
+                st4_stream(at(a.hx_w + q), o.hx);
+                st4_stream(at(a.hy_w + q), o.hy);
+                st4_stream(at(a.dz_b + q), o.dz);
+                st4_stream(at(a.ez_b + q), o.ez);
+                st4_stream(at(a.dz_a + q), c[K].dz);
+                st4_stream(at(a.ez_a + q), c[K].ez);
             }
             if (s == K) hx_top = o.hx;
             ezu = o.ez;
@@ -504,6 +544,31 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
         for (int i = 0; i < (HYR > 0 ? HYR : 1); ++i) hy_reg[i] = hy_reg_new[i];
         ezc = cur.ezu;
         cur = nxt;
+    };
+    // While the pipeline fills, stage s has nothing to do before iteration jlo + 2s - 2: level s is
+    // valid from row jlo + s on (a row goes stale per step), stage s reaches that row in iteration
+    // jlo + 2s - 1, and the hx of the row below it, which its D update needs, is the one thing the
+    // iteration before has to produce.  So the first 2(K-1) iterations run in pairs with 1, 2, ...
+    // K-1 stages: K(K-1) stage executions less of a wave's K(rows + 2K - 1), a fifth of the work of
+    // a band of 25 rows.  (A test per stage inside one loop costs that loop its register budget;
+    // the fully guarded copy, which few waves run, is large enough as it is and fills as before.)
+    int j = jlo;
+    if constexpr (FDTD_TB_SKIP_FILL && INY && K > 1) {
+        for_each_count(std::make_integer_sequence<int, K - 1>{}, [&](auto n) {
+#pragma unroll 1
+            for (int q = 0; q < 2; ++q, ++j) iterate(n, j);
+        });
+    }
+    if constexpr (FDTD_TB_UNROLL2 && INX && INY) {
+#pragma unroll 1
+        for (; j < jhi; j += 2) {
+            iterate(std::integral_constant<int, K>{}, j);
+            iterate(std::integral_constant<int, K>{}, j + 1);
+        }
+        if (j <= jhi) iterate(std::integral_constant<int, K>{}, j);
+    } else {
+#pragma unroll 1
+        for (; j <= jhi; ++j) iterate(std::integral_constant<int, K>{}, j);
     }
     };
 

@@ -1210,11 +1210,14 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         // (2048 x 1.45) is best or within 2 % of it (4096^2 435 Gcell-updates/s at 28 rows, 420 at 24, 419 at
         // 32; 5632^2 561 at 44, 530 at 52, 524 at 40; 7168^2 633 at 72, 596 at 80, 594 at 64); from 9216^2 up,
         // where 2048 waves saturate the memory system and the pass time follows the bytes, more and shorter
-        // waves balance the end of the launch better: 2.3 rounds, at most 176 rows (16384 x 8192: 750 at 120
-        // rows, 718 at 172; 9216^2 660 at 76, 674 at 88; 16384^2: 176 rows 790, 128 rows 775).
+        // waves balance the end of the launch better: at most 176 rows (16384^2: 176 rows 798, 128 rows 777,
+        // 256 rows 801), and below that just under two rounds (tools/roundscan2.sh, rounds 1.45 / 1.9 / 2.3 /
+        // 2.9: 9216^2 685 / 699 / 689 / 688 Gcell-updates/s, 11264^2 684 / 735 / 710 / 712, 12288^2 724 / 746 /
+        // 722 / 737, 8192 x 16384 781 / 808 / 788 / 786, the 8480 x 15680 tissue map 704 / 733 / 709 / 710).
         const long strips = ((c->nx + 3) / 4 + kTbOwnWords - 1) / kTbOwnWords;
         const long work = (long)c->sn * strips;
-        const double rounds = work < 60000 ? 1.2 : work < 330000 ? 1.45 : 2.3;
+        double rounds = work < 60000 ? 1.2 : work < 330000 ? 1.45 : 1.9;
+        if (const char *v = std::getenv("FDTD_TB_ROUNDS")) rounds = std::max(0.25, std::atof(v));
         const long want = (long)(work / (2048.0 * rounds) / 4.0 + 0.5) * 4;
         c->tb_rows = (int)std::min(176L, std::max(8L, want));
         if ((double)c->nx * c->sn < 6e6) c->tb_rows = (int)std::max(4L, std::min((long)c->tb_rows, (long)c->sn * strips / 2048));

@@ -8,11 +8,11 @@ d=json.load(open("gpurun_out/sm.json"))
 print("%-50s %9.2f us/step %8.1f Gcell/s"%(sys.argv[1], d["ms_per_step"]*1e3, d["value"]/1e3), flush=True)
 PY
 }
-for r in 0 144 152 160 168 184 192 208 224; do
+for r in 0 224 240 256 272 288 304; do
   if [ $r = 0 ]; then unset FDTD_TB_ROWS; else export FDTD_TB_ROWS=$r; fi
   run --steps 240 --warmup 16 || exit 1
 done
-for r in 0 88 96 104 120 128; do
+for r in 0 136 144 152 160 176 192; do
   if [ $r = 0 ]; then unset FDTD_TB_ROWS; else export FDTD_TB_ROWS=$r; fi
   run --tissue 32 --steps 140 --warmup 14 || exit 1
 done

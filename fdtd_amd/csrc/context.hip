@@ -1150,14 +1150,14 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
     c->kernel = opt->kernel;
     c->auto_kernel = c->kernel == FDTD_KERNEL_AUTO;
     if (c->kernel == FDTD_KERNEL_AUTO) {
-        // 2-D: the row-marching multi-step sweep from 9 M cells up; below, a pass of it is bound by
+        // 2-D: the row-marching multi-step sweep from 7.5 M cells up; below, a pass of it is bound by
         // the latency of its march, not by bandwidth, and the tiled multi-step sweep is faster
-        // (2048^2: 311 against 205 Gcell-updates/s, 1024^2: 211 against 81; 2896^2: 329 against 290; 3072^2:
-        // 315 against 316, 4096^2: 349 against 378, 8192^2: 378 against 647).
+        // (2048^2: 307 against 225 Gcell-updates/s, 1024^2: 211 against 81; 2560^2: 318 against 308; 2896^2:
+        // 330 against 370, 3072^2: 315 against 406).
         // Decided from the extents of the WHOLE grid, so that every slab of it takes the same kernel.
         // Smaller 2-D grids are bound by launch and memory latency: the tiled sweep advances them
         // several steps per launch out of registers and LDS.
-        c->kernel = !c->is2d() ? FDTD_KERNEL_FUSED : (double)p->nx * (double)p->ny >= 9e6 ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_TILE;
+        c->kernel = !c->is2d() ? FDTD_KERNEL_FUSED : (double)p->nx * (double)p->ny >= 7.5e6 ? FDTD_KERNEL_MULTISTEP : FDTD_KERNEL_TILE;
     }
     if (c->kernel == FDTD_KERNEL_TILE) {
         // the storage, the schedule and the halo protocol of the multi-step mode, another sweep kernel
@@ -1173,15 +1173,15 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
             set_error("FDTD_KERNEL_MULTISTEP and FDTD_KERNEL_TILE exist for the 2-D TMz mode only");
             return -3;
         }
-        // (3072^2: 316 Gcell-updates/s at 6 steps per pass, 294 at 8; 3584^2: 326 against 305; 4096^2: 361
-        // against 381);
+        // (steps per pass 6 / 7 / 8, tools/kscan.sh: 2896^2 365 / 370 / 352 Gcell-updates/s, 3072^2 395 / 406 /
+        // 388, 3328^2 406 / 426 / 412, 3584^2 424 / 469 / 469, 3840^2 421 / 450 / 499);
         // from the extents of the whole grid: every slab must advance the same number of steps
         // between two halo exchanges
-        const bool mid = (double)p->nx * (double)p->ny < 14e6;
+        const bool mid = (double)p->nx * (double)p->ny < 12e6;
         // (the tiled sweep from 3 M cells up, where its tiles take several rounds: 2048^2 329 at 6 steps per
         // launch, 312 at 8; 2896^2 347 against 333; 1024^2 205 against 210)
         const bool tile6 = c->tile && (double)p->nx * (double)p->ny >= 3e6;
-        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : ((mid && !c->tile) || tile6) ? 6 : kDefaultStepsPerPass;
+        c->tb_steps = opt->steps_per_pass > 0 ? opt->steps_per_pass : (mid && !c->tile) ? 7 : tile6 ? 6 : kDefaultStepsPerPass;
         c->spp_fixed = opt->steps_per_pass > 0 || (opt->slab_count > 0 && opt->slab_count != p->ny);
         if (c->tb_steps < (c->tile ? 1 : 2) || c->tb_steps > kMaxStepsPerPass) {
             set_error("steps_per_pass must be 2 .. 8 (FDTD_KERNEL_TILE: 1 .. 8)");

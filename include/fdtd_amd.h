@@ -62,7 +62,7 @@ enum { FDTD_ECOEF_REFERENCE = 0, FDTD_ECOEF_CONSISTENT = 1 };
  * steps out of registers and LDS and writes the Mur faces and the probe rows
  * itself: ONE launch per pass, for grids that are bound by launch and memory
  * latency instead of bandwidth.  steps_per_pass 1 .. 8.
- * AUTO: 2-D grids of 9 M cells or more MULTISTEP, smaller ones TILE (extents of
+ * AUTO: 2-D grids of 7.5 M cells or more MULTISTEP, smaller ones TILE (extents of
  * the WHOLE grid, so every slab of it decides alike), 3-D FUSED; a whole grid
  * whose MULTISTEP arrays do not fit into device memory falls back to FUSED, a
  * slab reports the error. */
@@ -76,7 +76,7 @@ typedef struct fdtd_options {
     int32_t slab_begin;  /* first global row of the slab axis held here (y in 2-D, z in 3-D) */
     int32_t slab_count;  /* rows held; 0 = the whole grid */
     int32_t chunk_rows;  /* rows marched by one workgroup of the fused sweep; 0 = default */
-    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (8, 6 below 14 M cells; a whole grid drops to
+    int32_t steps_per_pass; /* FDTD_KERNEL_MULTISTEP: 2 .. 8; 0 = default (8, 7 below 12 M cells; a whole grid drops to
                              * 7 once it holds material codes above 83, a slab or an explicit value never changes) */
     int32_t reserved[8];
 } fdtd_options;

@@ -661,7 +661,7 @@ def test_2d_material_codes_beyond_the_wide_table(oracle, dims, spp):
     """Material codes above 83: their table rows (48 bytes each) do not fit beside the parked rows of 8
     steps per pass.  Left to itself the library then takes 7 steps per pass; asked for 8 it takes the
     table of 16-byte rows with three waves per workgroup.  Same numbers either way."""
-    nx, ny = dims          # (the library chooses 8 steps per pass from 14 M cells up)
+    nx, ny = dims          # (the library chooses 8 steps per pass from 12 M cells up)
     kernel = B.KERNEL_MULTISTEP if spp == 0 else (B.KERNEL_MULTISTEP, spp)
     s, o = util.pair(oracle, (nx, ny, 1), [(nx // 2, ny // 2, 0), (3, 3, 0)], CON, kernel=kernel, sigma=0.2, eps_s=9.0,
                      eps_i=3.0, tau_d=2e-11)
@@ -814,10 +814,11 @@ def test_2d_tiled_sweep_4096_whole_field_and_auto_choice(oracle):
     assert np.abs(want[:, 1:3, 3]).max() > 0          # the wave reached the face probes
     assert np.array_equal(s.read_probes(0, steps).view(np.uint32), want.view(np.uint32))
     s.close()
-    # FDTD_KERNEL_AUTO: the tiled sweep below 9 M cells, the row-marching one from there on
-    # (steps per launch: 8, from 3 M cells up 6; the row-marching sweep 6 below 14 M cells, then 8)
+    # FDTD_KERNEL_AUTO: the tiled sweep below 7.5 M cells, the row-marching one from there on
+    # (steps per launch: 8, from 3 M cells up 6; the row-marching sweep 7 below 12 M cells, then 8)
     for dims, name, spp in (((1024, 1024), "fdtd2d_tile", 8), ((2048, 2048), "fdtd2d_tile", 6),
-                            ((3072, 3072), "fdtd2d_sweep_tb", 6), ((4096, 4096), "fdtd2d_sweep_tb", 8)):
+                            ((2896, 2896), "fdtd2d_sweep_tb", 7), ((3072, 3072), "fdtd2d_sweep_tb", 7),
+                            ((4096, 4096), "fdtd2d_sweep_tb", 8)):
         auto = fdtd_amd.Solver(fdtd_amd.make_params(*dims, 1, [(100, 100, 0)]), ecoef=CON)
         assert auto.sweep_kernel_name == name and auto.steps_per_pass == spp, dims
         auto.close()

@@ -1789,7 +1789,11 @@ int fdtd_sweep_work(const fdtd_ctx *c, int64_t *waves, int64_t *row_iterations)
     int64_t iters = 0;
     for (int64_t b = 0; b < bands; ++b) {
         int y0 = 0, y1 = 0;
-        if (tb_band_rows(a, b, y0, y1)) iters += y1 - y0 + 2 * K - 1;
+        if (!tb_band_rows(a, b, y0, y1)) continue;
+        // (the bands away from the y faces fill their pipeline with K(K-1) stage executions less: the
+        // worth of K - 1 iterations; the head and the last band run the fully guarded loop, which does not)
+        const bool guarded = (a.head_rows > 0 && b == 0) || (a.last_rows > 0 && b == bands - 1);
+        iters += y1 - y0 + (guarded ? 2 * K - 1 : K);
     }
     if (waves) *waves = bands * strips;
     if (row_iterations) *row_iterations = iters * strips;

@@ -202,8 +202,10 @@ int fdtd_profile_waves_begin(fdtd_ctx *ctx, int64_t capacity);
 int fdtd_profile_waves_read(fdtd_ctx *ctx, uint64_t *dst, int64_t capacity, int64_t *count);
 /* Shape of one launch of the main sweep over the slab: the waves it starts and
  * the row iterations they execute in all (a wave of the multi-step sweep
- * marches its rows plus 2 * steps_per_pass - 1 rows around them; the one-step
- * kernels handle one row per wave).  Input of issue-rate estimates. */
+ * marches its rows plus 2 * steps_per_pass - 1 rows around them, the first
+ * 2 * (steps_per_pass - 1) of which -- away from the y faces -- run half of the
+ * stages on average and count as steps_per_pass - 1; the one-step kernels
+ * handle one row per wave).  Input of issue-rate estimates. */
 int fdtd_sweep_work(const fdtd_ctx *ctx, int64_t *waves, int64_t *row_iterations);
 /* Name of the kernel that does the main sweep (as a profiler reports it). */
 const char *fdtd_sweep_kernel_name(const fdtd_ctx *ctx);

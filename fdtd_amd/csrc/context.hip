@@ -1399,6 +1399,7 @@ static int create_impl(const fdtd_params *p, const fdtd_options *opt, fdtd_ctx *
         c->rp[f] = c->rp_store[f] - first;
         if ((rc = upload_rp(c, f))) return rc;
     }
+    if (c->deep() && !c->tile) preload_sweep2d_tb(c->stream);
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }

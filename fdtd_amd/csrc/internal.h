@@ -340,6 +340,8 @@ void launch_sweep2d(const Sweep2D &a, void *stream);
 // Returns 0, or -1 when no kernel exists for `steps`.
 int launch_sweep2d_tb(const SweepTB &a, int steps, void *stream);
 const char *sweep2d_tb_kernel_name();
+// One empty workgroup of every instantiation of the multi-step sweep (their first launch is slow).
+void preload_sweep2d_tb(void *stream);
 // Returns 0, or -1 when the pass cannot be tiled (steps outside 1 .. kMaxStepsPerPass, no rows).
 int launch_sweep2d_tile(const SweepTile &t, void *stream);
 // Tile height the launcher takes for a launch over `rows_of_launch` rows: 32, 64, or 642 (64 rows, two words per thread).

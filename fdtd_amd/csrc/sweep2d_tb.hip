@@ -93,6 +93,7 @@ template <int K, bool ONE, bool PLAIN, bool WIDE>
 __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_sweep_tb(const SweepTB a)
 {
     constexpr int OWN = kTbOwnWords, LEFT = kTbHaloWords, WPB = tb_waves<K, ONE, WIDE>();
+    if (a.nwaves == 0) return; // the launch that loads the kernel when a context is created
     // Grids with several materials: the coefficient table sits in LDS, where a lookup per cell and
     // stage costs a fraction of a cached global load.
     __shared__ MatEntry tab[(ONE || WIDE) ? 1 : FDTD_MAX_CODES];
@@ -626,7 +627,25 @@ template <int K> int launch_k(const SweepTB &a, hipStream_t stream)
     return 0;
 }
 
+// The first launch of an instantiation costs a quarter of a millisecond more than the later ones
+// (16384^2: 2.92 ms against 2.67), whichever kernels ran before it.  A context pays that when it is
+// created: one workgroup of every instantiation its passes can take -- full passes, remainder passes,
+// either table form --, which leaves at its first instruction.
+template <int K> void preload_k(hipStream_t stream)
+{
+    SweepTB z = {};
+    hipLaunchKernelGGL((fdtd2d_sweep_tb<K, true, true, false>), dim3(1), dim3(tb_waves<K, true, false>() * 64), 0, stream, z);
+    hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, true>), dim3(1), dim3(tb_waves<K, false, true>() * 64), 0, stream, z);
+    hipLaunchKernelGGL((fdtd2d_sweep_tb<K, false, true, false>), dim3(1), dim3(tb_waves<K, false, false>() * 64), 0, stream, z);
+}
+
 } // namespace
+
+void preload_sweep2d_tb(void *stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    preload_k<2>(s), preload_k<3>(s), preload_k<4>(s), preload_k<5>(s), preload_k<6>(s), preload_k<7>(s), preload_k<8>(s);
+}
 
 int launch_sweep2d_tb(const SweepTB &a, int steps, void *stream)
 {

@@ -630,7 +630,9 @@ template <int K> int launch_k(const SweepTB &a, hipStream_t stream)
 // The first launch of an instantiation costs a quarter of a millisecond more than the later ones
 // (16384^2: 2.92 ms against 2.67), whichever kernels ran before it.  A context pays that when it is
 // created: one workgroup of every instantiation its passes can take -- full passes, remainder passes,
-// either table form --, which leaves at its first instruction.
+// either table form --, which leaves at its first instruction.  (Asking for the kernels' attributes
+// instead loads the code object but leaves the first launch of each as slow as before.)
+// FDTD_TB_PRELOAD=0 turns this off: a profiler's per-kernel averages then hold real passes only.
 template <int K> void preload_k(hipStream_t stream)
 {
     SweepTB z = {};
@@ -643,6 +645,8 @@ template <int K> void preload_k(hipStream_t stream)
 
 void preload_sweep2d_tb(void *stream)
 {
+    static const bool off = std::getenv("FDTD_TB_PRELOAD") && !std::atoi(std::getenv("FDTD_TB_PRELOAD"));
+    if (off) return;
     hipStream_t s = (hipStream_t)stream;
     preload_k<2>(s), preload_k<3>(s), preload_k<4>(s), preload_k<5>(s), preload_k<6>(s), preload_k<7>(s), preload_k<8>(s);
 }

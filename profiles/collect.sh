@@ -8,6 +8,9 @@ tag=${1:-r01}
 shift || true
 args=${*:---steps 48 --warmup 8 --no-cpu-baseline}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+# (without the 21 empty launches with which a context loads the instantiations of the multi-step sweep:
+# they carry the kernels' names and would enter the per-kernel averages)
+export FDTD_TB_PRELOAD=0
 out=gpurun_out/$tag
 mkdir -p "$out"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python bench.py $args > "$out/bench_trace.json" 2> "$out/trace.err" || { tail -5 "$out/trace.err"; exit 1; }

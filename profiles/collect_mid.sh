@@ -4,6 +4,7 @@
 # pass (tools/wave_timeline.py).  Output under gpurun_out/r03_mid/<grid>_rows<r>/.
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+export FDTD_TB_PRELOAD=0 # (no empty launches under the kernels' names in the per-kernel averages)
 while read nx ny k rows; do
   for r in $rows; do
     out=gpurun_out/r03_mid/${nx}x${ny}_rows$r

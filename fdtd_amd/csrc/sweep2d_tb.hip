@@ -18,10 +18,12 @@
 // per step, hence K <= 8; registers and LDS are full at K = 8 too).  A launch
 // covers a range of rows (a pass may be split into a launch for the rows next
 // to the slab edges and one for the rest, so that the halo exchange of the
-// former overlaps the latter).  The wave marches upwards; in iteration j stage s works on row j - (s - 1), so the
-// pipeline is primed K rows below the first owned row and drained K - 1 rows
-// above the last: rows outside the owned window are recomputed, not
-// communicated.  Because neighbouring waves re-read the rows a wave writes, the
+// former overlaps the latter).  The wave marches upwards; in iteration j stage
+// s works on row j - (s - 1), so the pipeline is primed K rows below the first
+// owned row and drained K - 1 rows above the last: rows outside the owned
+// window are recomputed, not communicated.  While the pipeline fills, only the
+// stages whose rows hold valid data run (see the march below).  Because
+// neighbouring waves re-read the rows a wave writes, the
 // output levels live in arrays of their own (no in-place update), and H has a
 // read and a write generation.
 //
@@ -68,16 +70,14 @@ template <bool INX, bool INY> struct LoopMode {
     static constexpr bool inx = INX, iny = INY;
 };
 
+// 1: the first 2(K-1) iterations of a wave run only the stages that have valid rows; 0: all K stages.
+#ifndef FDTD_TB_SKIP_FILL
+#define FDTD_TB_SKIP_FILL 1
+#endif
 // Waves per workgroup: four, except for the 16-byte-row table variant at K = 8, whose 20 KB of parked
 // rows per wave plus the 4 KB table allow three (two workgroups per CU either way).  The 48-byte-row
 // variant holds at most kWideTableRowsK8 rows there and keeps one more hy row in registers, which
 // leaves room for four waves: 2 x (4 x 19 KB + 4 KB) = 160 KB.
-#ifndef FDTD_TB_SKIP_FILL
-#define FDTD_TB_SKIP_FILL 1
-#endif
-#ifndef FDTD_TB_UNROLL2
-#define FDTD_TB_UNROLL2 0
-#endif
 #ifndef FDTD_TB8_TABLE_WAVES
 #define FDTD_TB8_TABLE_WAVES 3
 #endif
@@ -560,17 +560,11 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
             for (int q = 0; q < 2; ++q, ++j) iterate(n, j);
         });
     }
-    if constexpr (FDTD_TB_UNROLL2 && INX && INY) {
+    // (The hand-over of a stage's state to the next iteration is a register copy -- 144 moves per
+    // row at K = 8 -- that a loop unrolled twice would not need; it needs more than the 256 registers
+    // two waves per SIMD leave: 11 scratch operations per pair of rows.)
 #pragma unroll 1
-        for (; j < jhi; j += 2) {
-            iterate(std::integral_constant<int, K>{}, j);
-            iterate(std::integral_constant<int, K>{}, j + 1);
-        }
-        if (j <= jhi) iterate(std::integral_constant<int, K>{}, j);
-    } else {
-#pragma unroll 1
-        for (; j <= jhi; ++j) iterate(std::integral_constant<int, K>{}, j);
-    }
+    for (; j <= jhi; ++j) iterate(std::integral_constant<int, K>{}, j);
     };
 
     // Three copies of the loop: guards folded in both directions (most waves), in y only (the strips on

@@ -358,13 +358,14 @@ def test_2d_multi_step_random_cases(oracle, seed, kind):
 
 
 @pytest.mark.parametrize("k", [2, 5, 8])
-@pytest.mark.parametrize("rows", [4, 9, 16])
+@pytest.mark.parametrize("rows", [2, 4, 9, 16])
 def test_2d_multi_step_short_bands_on_the_y_faces(oracle, monkeypatch, k, rows):
     """Launches that touch a y face start with a band of 2K+1 rows and end with one of K+2 when the
     grid is tall enough for it (2 * rows + 3K + 3 rows): grid heights on either side of that
     threshold, band heights that do and do not divide the rest, Mur with random rp on all four
     faces, tissue codes, sources and probes inside the two short bands, next to them and in the
-    x-face strips -- every field bit for bit against the oracle, probe series included."""
+    x-face strips -- every field bit for bit against the oracle, probe series included.  (Bands of two
+    rows: a wave then runs three iterations with all its stages after the 2(K-1) in which its pipeline fills.)"""
     monkeypatch.setenv("FDTD_TB_ROWS", str(rows))
     limit = 2 * rows + 3 * k + 3
     for ny in (limit - 1, limit, limit + 7, 4 * limit + 3):

@@ -586,6 +586,46 @@ def test_2d_multi_step_random_cases_many_strips_and_bands(oracle, seed, kind):
 
 
 @pytest.mark.timeout(300)
+def test_2d_multi_step_long_run_with_the_library_s_own_choices(oracle):
+    """1000 steps of a 3100 x 2500 grid (7.75 M cells: the row-marching sweep at the steps per pass and
+    the band height the library chooses by itself), tissue codes in blocks, Mur with random rp, three
+    sources, probes; calls of irregular length, so full passes, remainder passes of every length and
+    single steps alternate for a long time.  Fields every 125 steps and the probe series of the whole
+    run, bit for bit."""
+    nx, ny, steps = 3100, 2500, 1000
+    rng = np.random.default_rng(424242)
+    srcs = [(nx // 2, ny // 2, 0), (7, ny - 9, 0), (nx - 3, 40, 0)]
+    s, o = util.pair(oracle, (nx, ny, 1), srcs, CON, sigma=0.2, eps_s=9.0, eps_i=3.0, tau_d=2e-11)
+    assert s.sweep_kernel_name == "fdtd2d_sweep_tb" and s.steps_per_pass == 7
+    blocks = rng.integers(0, len(util.RIKEN_LIKE), size=(1, (ny + 31) // 32, (nx + 31) // 32), dtype=np.uint8)
+    codes = np.ascontiguousarray(np.repeat(np.repeat(blocks, 32, axis=1), 32, axis=2)[:, :ny, :nx])
+    util.set_materials(s, o, codes)
+    for face in (0, 1, 3, 4):
+        rp = (1.0 + 60.0 * rng.random(o.rp(face).size)).astype(np.float32)
+        s.set_rp(face, rp)
+        o.set_rp(face, rp)
+    probes = [(nx // 2, ny // 2, 0), (0, 0, 0), (nx - 1, ny - 1, 0), (1000, 3, 0), (nx // 2 + 200, ny // 2 - 100, 0)]
+    s.set_probes(probes, capacity=steps)
+    series = np.zeros((steps, len(probes), 4), dtype=np.float32)
+    peak = util.Peak()
+    done = 0
+    while done < steps:
+        n = int(min(steps - done, rng.integers(1, 60)))
+        for i in range(n):
+            o.step(1, threads=16)
+            peak.update(o, util.fields_of(s))
+            for q, (x, y, _) in enumerate(probes):
+                series[done + i, q] = [o.field(f)[0, y, x] for f in (B.HX, B.HY, B.DZ, B.EZ)]
+        s.step(n)
+        if (done + n) // 125 != done // 125 or done + n == steps:
+            assert util.compare(s, o, peak, f"long run, step {done + n}") == 0
+        done += n
+    assert np.abs(series[:, 0, 3]).max() > 0
+    assert np.array_equal(s.read_probes(0, steps).view(np.uint32), series.view(np.uint32))
+    s.close()
+
+
+@pytest.mark.timeout(300)
 @pytest.mark.parametrize("spp", [0, 5])
 def test_2d_two_processes_one_gpu_host_transport(oracle, tmp_path, spp):
     """Two ranks (two processes, both on GPU 0) run the slab protocol with the HIP engine

@@ -489,16 +489,6 @@ __global__ __launch_bounds__((tb_waves<K, ONE, WIDE>() * 64), 2) void fdtd2d_swe
                                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfq[1]), s - 1)),
                                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfq[2]), s - 1)),
                                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cfq[3]), s - 1))};
-#ifdef FDTD_DEBUG_CFQ
-                    {
-                        const int y = g.gy0 + r;
-                        if (wave_xe && w == xe_w && y >= 1 && y <= g.gny - 2) {
-                            const f4 ref = ((const f4 *)a.cfxe)[y];
-                            if (ref.x != cfx.x || ref.y != cfx.y)
-                                printf("cfq mismatch band %d strip %d j %d s %d r %d: got %g %g want %g %g (lane %d)\n", band, strip, j, s, r, cfx.x, cfx.y, ref.x, ref.y, lane);
-                        }
-                    }
-#endif
                     mur_x(o.ez, c[s].ez, r, cfx);
                 }
                 if (!INY && (y == g.gny - 1 || y == 1)) {
